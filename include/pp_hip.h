@@ -1,0 +1,132 @@
+/*
+ * pp_hip.h -- C ABI of libpphip.so: the piecewise-polynomial fully-connected
+ * layer (continuous + discontinuous Lagrange layers) as hand-written gfx950
+ * HIP kernels.
+ *
+ * What it replaces.  In the reference the whole path is Python calling the
+ * third-party package high-order-layers-torch (not vendored, pyproject.toml:21);
+ * there is no FFI to mirror, so each entry point cites the reference call site
+ * whose work it performs.  All of them sit behind
+ *     high_order_fc_layers(layer_type, n, in_features, out_features, segments, ...)
+ *         /root/reference/language_interpolation/networks.py:399-426, :799-806
+ *     HighOrderMLP(...).forward
+ *         /root/reference/language_interpolation/networks.py:866-882,
+ *         /root/reference/language_interpolation/state_space_network.py:186-196
+ * and the autograd backward that Lightning's loss.backward() triggers
+ * (networks.py:122-132, :164-165).
+ *
+ * Conventions (every entry point):
+ *   - extern "C", returns 0 on success, a negative PP_ERR_* on a rejected
+ *     argument, or a positive hipError_t on a launch failure; never throws.
+ *   - all data pointers are DEVICE pointers, fp32, contiguous row-major,
+ *     16-byte aligned; the caller owns every buffer, the library allocates
+ *     nothing and keeps no state between calls (safe from any host thread --
+ *     autograd calls backward from its own engine thread).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
+ *     stream-ordered; no call synchronises the device.
+ *   - B rows (samples), I in_features, O out_features, n nodes per segment,
+ *     S segments, `discontinuous` 0/1, `length` the layer's `length`/`scale`
+ *     (2.0 at every reference call site).
+ *     K = n*S (discontinuous) or (n-1)*S+1 (continuous, n >= 2).
+ *   - weights are taken in the KERNEL layout w_t[I][K][O] (out contiguous):
+ *     the n active rows of one (sample, input) pair are one contiguous n*O
+ *     slab.  The reference's parameter layout is w[O][I][K];
+ *     pp_transpose_w_f32 / pp_transpose_wt_f32 convert (the Python module
+ *     stores its nn.Parameter with logical shape [O,I,K] and physical layout
+ *     [I,K,O], so no conversion runs in the training loop).
+ *   - `nodes`: HOST pointer to n floats (the Chebyshev-Lobatto nodes exactly as
+ *     the caller's framework computed them in fp32), or NULL for the library's
+ *     own -cos(pi k/(n-1))*length/2.
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_MAX_N 8 /* nodes per segment supported by the kernels */
+
+enum {
+  PP_OK = 0,
+  PP_ERR_NULL = -1,      /* a required pointer is NULL */
+  PP_ERR_SHAPE = -2,     /* B/I/O/n/S out of range (n > PP_MAX_N, continuous n < 2, ...) */
+  PP_ERR_ALIGN = -3,     /* a pointer is not 16-byte aligned */
+  PP_ERR_WORKSPACE = -4, /* workspace missing or smaller than pp_workspace_bytes() */
+  PP_ERR_METHOD = -5,    /* unknown / inapplicable method id */
+  PP_ERR_RANGE = -6      /* index arithmetic would overflow int32 */
+};
+
+/* method ids */
+enum {
+  PP_METHOD_AUTO = 0,
+  PP_FWD_GATHER = 1,  /* wavefront-cooperative gather of the active slab (any S) */
+  PP_FWD_DENSE = 2,   /* expanded-basis x weight on f32 MFMA (small K only) */
+  PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
+  PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
+  PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
+  PP_BWD_X_GATHER = 1,
+  PP_BWD_X_DENSE = 2
+};
+
+/* Library version (major*10000 + minor*100 + patch). No reference counterpart. */
+int pp_version(void);
+
+/* Text for a return code (static storage). */
+const char* pp_error_string(int code);
+
+/* A1 of SURVEY.md 8(a): seg[b,i] = clamp(trunc(((x+L/2)/L)*S), 0, S-1), fp32 in
+ * that op order.  Replaces `Piecewise.forward` step 1 of high-order-layers-torch
+ * as reached from networks.py:799-806.  seg: int32[B*I]. */
+int pp_segment_ids_f32(const float* x, int32_t* seg, int B, int I, int S, float length,
+                       void* stream);
+
+/* Forward, A1-A4 fused: y[B,O] = out_scale * sum_i sum_j l_j(xi[b,i]) * w_t[i, s*stride+j, :].
+ * Replaces the layer's forward as called from nn.Sequential inside HighOrderMLP
+ * (networks.py:160-162 -> :866-882) and from reshape_apply (utils.py:36).
+ * seg_out: optional int32[B*I] (NULL to skip) for the bit-exact index check.
+ * out_scale: 1.0, or 1/I for rescale_output=True. */
+int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
+                   int O, int n, int S, int discontinuous, float length, const float* nodes,
+                   float out_scale, int method, void* stream);
+
+/* Backward w.r.t. the input (A4' of SURVEY.md 8(a)):
+ * gx[b,i] = out_scale * (L/(x_max-x_min)) * sum_o gy[b,o] * sum_j l'_j(xi) * w_t[i, s*stride+j, o].
+ * Replaces autograd's backward through gather/einsum (loss.backward(), networks.py:164-165).
+ * n == 1 gives gx == 0 (written, not skipped). */
+int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, float* gx, int B,
+                          int I, int O, int n, int S, int discontinuous, float length,
+                          const float* nodes, float out_scale, int method, void* stream);
+
+/* Bytes of scratch pp_backward_weight_f32 needs for `method` (0 for methods
+ * that need none).  Scratch is caller-owned device memory, 16-byte aligned,
+ * contents undefined on entry and exit. */
+size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method);
+
+/* Backward w.r.t. the weights (A4'): gw_t[i,k,o] = out_scale * sum_{(b,j): s[b,i]*stride+j==k}
+ * gy[b,o] * l_j(xi[b,i]); DENSE result in the kernel layout [I][K][O], every
+ * element written (untouched weights get 0), the callee does any zero-fill it
+ * needs.  Replaces autograd's index_put_(accumulate=True) scatter into w.grad.
+ * PP_BWD_W_SORT is bitwise reproducible only up to the order of rows inside a
+ * bucket; PP_BWD_W_ATOMIC depends on atomic arrival order. */
+int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* workspace,
+                           size_t workspace_bytes, int B, int I, int O, int n, int S,
+                           int discontinuous, float length, const float* nodes, float out_scale,
+                           int method, void* stream);
+
+/* w[O][I][K] (reference parameter layout, e.g. a checkpoint of the reference)
+ * -> w_t[I][K][O] and back.  No reference counterpart (layout adaptor). */
+int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream);
+int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* stream);
+
+/* Which method PP_METHOD_AUTO resolves to for a shape (for logs and tests).
+ * pass: 0 forward, 1 backward-input, 2 backward-weight. */
+int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libpphip.so (C ABI: include/pp_hip.h).
+
+The library is built in-tree by ``language_interpolation_amd/csrc/Makefile``
+(``__graft_entry__.build()`` drives it).  There is no fallback: if the shared
+object is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpphip.so")
+
+PP_MAX_N = 8
+
+# method ids (include/pp_hip.h)
+METHOD_AUTO = 0
+FWD_GATHER, FWD_DENSE = 1, 2
+BWD_X_GATHER, BWD_X_DENSE = 1, 2
+BWD_W_ATOMIC, BWD_W_SORT, BWD_W_DENSE = 1, 2, 3
+
+FWD_METHODS = {"auto": 0, "gather": 1, "dense": 2}
+BWD_X_METHODS = {"auto": 0, "gather": 1, "dense": 2}
+BWD_W_METHODS = {"auto": 0, "atomic": 1, "sort": 2, "dense": 3}
+
+# every symbol include/pp_hip.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    "pp_version": (c_int, []),
+    "pp_error_string": (ctypes.c_char_p, [c_int]),
+    "pp_auto_method": (c_int, [c_int] * 7),
+    "pp_segment_ids_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),
+    "pp_forward_f32": (
+        c_int,
+        [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
+    ),
+    "pp_backward_input_f32": (
+        c_int,
+        [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
+    ),
+    "pp_workspace_bytes": (c_size_t, [c_int] * 7),
+    "pp_backward_weight_f32": (
+        c_int,
+        [_P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float,
+         c_int, _P],
+    ),
+    "pp_transpose_w_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "pp_transpose_wt_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+}
+
+_lib = None
+
+
+class PPHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libpphip.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PPHipError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or __graft_entry__.build()). There is no CPU or PyTorch fallback for this layer."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().pp_error_string(code)
+        raise PPHipError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

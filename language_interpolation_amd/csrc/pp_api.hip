@@ -1,0 +1,199 @@
+// C ABI of libpphip.so (declared in include/pp_hip.h): argument validation,
+// node table construction and method dispatch.  No allocation, no
+// synchronisation, no global state.
+#include <cmath>
+#include <cstdint>
+
+#include "pp_internal.h"
+
+namespace {
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int make_shape(PPShape& sh, int B, int I, int O, int n, int S, int disc, float length,
+               float out_scale) {
+  if (B < 1 || I < 1 || O < 1 || S < 1 || n < 1 || n > PP_MAX_N) return PP_ERR_SHAPE;
+  if (!disc && n < 2) return PP_ERR_SHAPE;  // continuous needs >= 2 nodes per segment
+  if (!(length > 0.0f)) return PP_ERR_SHAPE;
+  if (S > (1 << 24)) return PP_ERR_SHAPE;  // float(S) must be exact
+  const long K = disc ? (long)n * S : (long)(n - 1) * S + 1;
+  if ((long)B * I >= (1L << 31) || (long)B * O >= (1L << 31) || (long)I * K >= (1L << 31) ||
+      K >= (1L << 31))
+    return PP_ERR_RANGE;
+  sh.B = B; sh.I = I; sh.O = O; sh.n = n; sh.S = S; sh.K = (int)K;
+  sh.stride = disc ? n : n - 1;
+  sh.disc = disc ? 1 : 0;
+  sh.length = length;
+  sh.half = 0.5f * length;
+  sh.Sf = (float)S;
+  sh.out_scale = out_scale;
+  return PP_OK;
+}
+
+void make_basis(BasisTab& tab, int n, float length, const float* nodes) {
+  for (int j = 0; j < PP_MAX_N; ++j) { tab.X[j] = 0.0f; tab.invden[j] = 1.0f; }
+  if (nodes) {
+    for (int j = 0; j < n; ++j) tab.X[j] = nodes[j];
+  } else if (n > 1) {
+    for (int j = 0; j < n; ++j) {
+      float a = (float)j * (float)M_PI / (float)(n - 1);
+      tab.X[j] = (0.5f * length) * (-cosf(a));
+    }
+  }
+  for (int j = 0; j < n; ++j) {
+    double den = 1.0;
+    for (int m = 0; m < n; ++m)
+      if (m != j) den *= (double)tab.X[j] - (double)tab.X[m];
+    tab.invden[j] = (float)(1.0 / den);
+  }
+}
+
+int hip_rc(hipError_t e) { return e == hipSuccess ? PP_OK : (int)e; }
+
+// K small enough that the expanded basis Phi[B, I*K] is "genuinely dense"
+// (n/K nonzero per input) and the contraction wide enough to feed MFMA tiles.
+bool dense_preferred(const PPShape& sh) {
+  return pp_dense_supported(sh) && sh.K <= 8 && sh.I >= 32 && sh.O >= 32;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pp_version(void) { return 100; }
+
+const char* pp_error_string(int code) {
+  switch (code) {
+    case PP_OK: return "ok";
+    case PP_ERR_NULL: return "required pointer is NULL";
+    case PP_ERR_SHAPE: return "shape out of range (need B,I,O,S >= 1, 1 <= n <= 8, continuous n >= 2, length > 0)";
+    case PP_ERR_ALIGN: return "pointer is not 16-byte aligned";
+    case PP_ERR_WORKSPACE: return "workspace missing or too small (see pp_workspace_bytes)";
+    case PP_ERR_METHOD: return "unknown or inapplicable method for this shape";
+    case PP_ERR_RANGE: return "index range exceeds int32";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous) {
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f);
+  if (rc != PP_OK) return rc;
+  const bool dense = dense_preferred(sh);
+  switch (pass) {
+    case 0: return dense ? PP_FWD_DENSE : PP_FWD_GATHER;
+    case 1: return dense ? PP_BWD_X_DENSE : PP_BWD_X_GATHER;
+    case 2:
+      if (dense) return PP_BWD_W_DENSE;
+      return pp_sort_supported(sh) ? PP_BWD_W_SORT : PP_BWD_W_ATOMIC;
+    default: return PP_ERR_METHOD;
+  }
+}
+
+int pp_segment_ids_f32(const float* x, int32_t* seg, int B, int I, int S, float length,
+                       void* stream) {
+  if (!x || !seg) return PP_ERR_NULL;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, 1, 1, S, 1, length, 1.0f);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_segment_ids(x, seg, sh, (hipStream_t)stream));
+}
+
+int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
+                   int O, int n, int S, int discontinuous, float length, const float* nodes,
+                   float out_scale, int method, void* stream) {
+  if (!x || !w_t || !y) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(w_t) || !aligned16(y)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  if (method == PP_METHOD_AUTO) method = dense_preferred(sh) ? PP_FWD_DENSE : PP_FWD_GATHER;
+  hipStream_t st = (hipStream_t)stream;
+  if (method == PP_FWD_GATHER) return hip_rc(pp_launch_fwd_gather(x, w_t, y, seg_out, sh, tab, st));
+  if (method == PP_FWD_DENSE) {
+    if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
+    return hip_rc(pp_launch_fwd_dense(x, w_t, y, seg_out, sh, tab, st));
+  }
+  return PP_ERR_METHOD;
+}
+
+int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, float* gx, int B,
+                          int I, int O, int n, int S, int discontinuous, float length,
+                          const float* nodes, float out_scale, int method, void* stream) {
+  if (!x || !gy || !w_t || !gx) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(gy) || !aligned16(w_t) || !aligned16(gx)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  if (method == PP_METHOD_AUTO) method = dense_preferred(sh) ? PP_BWD_X_DENSE : PP_BWD_X_GATHER;
+  hipStream_t st = (hipStream_t)stream;
+  if (method == PP_BWD_X_GATHER)
+    return hip_rc(pp_launch_bwd_input_gather(x, gy, w_t, gx, sh, tab, st));
+  if (method == PP_BWD_X_DENSE) {
+    if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
+    return hip_rc(pp_launch_bwd_input_dense(x, gy, w_t, gx, sh, tab, st));
+  }
+  return PP_ERR_METHOD;
+}
+
+size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method) {
+  PPShape sh;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous);
+  if (method == PP_BWD_W_SORT) return pp_sort_supported(sh) ? pp_sort_workspace_bytes(sh) : 0;
+  if (method == PP_BWD_W_DENSE)
+    return pp_dense_supported(sh) ? pp_dense_bwd_weight_workspace_bytes(sh) : 0;
+  return 0;
+}
+
+int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* workspace,
+                           size_t workspace_bytes, int B, int I, int O, int n, int S,
+                           int discontinuous, float length, const float* nodes, float out_scale,
+                           int method, void* stream) {
+  if (!x || !gy || !gw_t) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(gy) || !aligned16(gw_t) || !aligned16(workspace))
+    return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous);
+  hipStream_t st = (hipStream_t)stream;
+  switch (method) {
+    case PP_BWD_W_ATOMIC:
+      return hip_rc(pp_launch_bwd_weight_atomic(x, gy, gw_t, sh, tab, st));
+    case PP_BWD_W_SORT: {
+      if (!pp_sort_supported(sh)) return PP_ERR_METHOD;
+      const size_t need = pp_sort_workspace_bytes(sh);
+      if (!workspace || workspace_bytes < need) return PP_ERR_WORKSPACE;
+      return hip_rc(pp_launch_bwd_weight_sort(x, gy, gw_t, workspace, sh, tab, st));
+    }
+    case PP_BWD_W_DENSE: {
+      if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
+      const size_t need = pp_dense_bwd_weight_workspace_bytes(sh);
+      if (need && (!workspace || workspace_bytes < need)) return PP_ERR_WORKSPACE;
+      return hip_rc(pp_launch_bwd_weight_dense(x, gy, gw_t, workspace, sh, tab, st));
+    }
+    default:
+      return PP_ERR_METHOD;
+  }
+}
+
+int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream) {
+  if (!w || !w_t) return PP_ERR_NULL;
+  if (O < 1 || I < 1 || K < 1 || (long)I * K >= (1L << 31)) return PP_ERR_SHAPE;
+  return hip_rc(pp_launch_transpose(w, w_t, O, I * K, (hipStream_t)stream));
+}
+
+int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* stream) {
+  if (!w || !w_t) return PP_ERR_NULL;
+  if (O < 1 || I < 1 || K < 1 || (long)I * K >= (1L << 31)) return PP_ERR_SHAPE;
+  return hip_rc(pp_launch_transpose(w_t, w, I * K, O, (hipStream_t)stream));
+}
+
+}  // extern "C"

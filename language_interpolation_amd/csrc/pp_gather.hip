@@ -1,0 +1,371 @@
+// Gather path: wavefront-cooperative gather of the active weight slab.
+//
+// Layout: w_t[I][K][O].  For one (sample b, input i) pair the n active weight
+// rows k = s*stride .. s*stride+n-1 are ONE contiguous n*O slab, so a wavefront
+// whose lanes span `out` reads it as full-width coalesced rows.  The per-(b,i)
+// scalar work (segment id, local coordinate, Lagrange basis -- A1..A3 of
+// SURVEY.md 8a) is done lane-parallel over 64 inputs at a time and then handed
+// to the whole wavefront with v_readlane, so it is computed once per pair, not
+// once per output.
+//
+// Replaces: Piecewise.forward of high-order-layers-torch as called through
+// HighOrderMLP / high_order_fc_layers (networks.py:399-426, :799-806, :866-882)
+// and its autograd backward.
+#include "pp_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// A1 only: segment ids (for the bit-exact index check)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_segment_ids_kernel(const float* __restrict__ x,
+                                                             int32_t* __restrict__ seg, long total,
+                                                             float length, float half, float Sf,
+                                                             int S) {
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long step = (long)gridDim.x * 256;
+  for (; idx < total; idx += step) seg[idx] = pp_segment(x[idx], length, half, Sf, S);
+}
+
+// ---------------------------------------------------------------------------
+// forward
+//   grid.x: groups of 4*RW rows (4 waves per block, RW rows per wave)
+//   grid.y: chunks of 64*V outputs
+// ---------------------------------------------------------------------------
+template <int N, int V, int RW>
+__global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ wt,
+                                                            float* __restrict__ y,
+                                                            int32_t* __restrict__ seg_out,
+                                                            PPShape sh, BasisTab tab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  if (row0 >= sh.B) return;  // wave-uniform; no block barrier below
+  const int o = (blockIdx.y * 64 + lane) * V;
+  const bool o_ok = o < sh.O;
+  const int oc = o_ok ? o : sh.O - V;  // clamp: every lane loads valid memory
+  const bool write_seg = (seg_out != nullptr) && (blockIdx.y == 0);
+
+  float acc[RW][V];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[r][v] = 0.0f;
+
+  for (int i0 = 0; i0 < sh.I; i0 += 64) {
+    const int i = i0 + lane;
+    int koff[RW];
+    float l[RW][N];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int b = min(row0 + r, sh.B - 1);
+      const bool valid = i < sh.I;
+      const float xv = valid ? x[(size_t)b * sh.I + i] : 0.0f;
+      const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
+      const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
+      pp_lagrange<N>(xi, tab, l[r]);
+      koff[r] = (valid ? i : 0) * sh.K + s * sh.stride;
+      if (write_seg && valid && row0 + r < sh.B) seg_out[(size_t)b * sh.I + i] = s;
+    }
+    const int cnt = min(64, sh.I - i0);
+    for (int ii = 0; ii < cnt; ++ii) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int ko = pp_readlane_i(koff[r], ii);
+        const float* p = wt + (size_t)ko * sh.O + oc;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float lj = pp_readlane_f(l[r][j], ii);
+          PPVec<V> wv;
+          wv.load(p + (size_t)j * sh.O);
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[r][v] = fmaf(lj, wv.v[v], acc[r][v]);
+        }
+      }
+    }
+  }
+  if (o_ok) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      if (row0 + r < sh.B) {
+        PPVec<V> out;
+#pragma unroll
+        for (int v = 0; v < V; ++v) out.v[v] = acc[r][v] * sh.out_scale;
+        out.store(y + (size_t)(row0 + r) * sh.O + o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward w.r.t. the input: one wave per row; lanes span `out`, one wave
+// reduction per (row, input, out-chunk).
+// ---------------------------------------------------------------------------
+template <int N, int V>
+__global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ gy,
+                                                                  const float* __restrict__ wt,
+                                                                  float* __restrict__ gx,
+                                                                  PPShape sh, BasisTab tab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= sh.B) return;
+  const int nchunk = (sh.O + 64 * V - 1) / (64 * V);
+
+  for (int i0 = 0; i0 < sh.I; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < sh.I;
+    const float xv = valid ? x[(size_t)b * sh.I + i] : 0.0f;
+    const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
+    float dxi_dx;
+    const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, &dxi_dx);
+    float l[N], dl[N];
+    pp_lagrange_d<N>(xi, tab, l, dl);
+    const float chain = dxi_dx * sh.out_scale;
+#pragma unroll
+    for (int j = 0; j < N; ++j) dl[j] *= chain;
+    const int koff = (valid ? i : 0) * sh.K + s * sh.stride;
+
+    float res = 0.0f;
+    const int cnt = min(64, sh.I - i0);
+    for (int c = 0; c < nchunk; ++c) {
+      const int o = (c * 64 + lane) * V;
+      const bool o_ok = o < sh.O;
+      const int oc = o_ok ? o : sh.O - V;
+      PPVec<V> g;
+      g.load(gy + (size_t)b * sh.O + oc);
+      if (!o_ok) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) g.v[v] = 0.0f;
+      }
+      for (int ii = 0; ii < cnt; ++ii) {
+        const int ko = pp_readlane_i(koff, ii);
+        const float* p = wt + (size_t)ko * sh.O + oc;
+        float part = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float cj = pp_readlane_f(dl[j], ii);
+          PPVec<V> wv;
+          wv.load(p + (size_t)j * sh.O);
+          float d = 0.0f;
+#pragma unroll
+          for (int v = 0; v < V; ++v) d = fmaf(wv.v[v], g.v[v], d);
+          part = fmaf(cj, d, part);
+        }
+        const float tot = pp_wave_sum(part);
+        if (lane == ii) res += tot;
+      }
+    }
+    if (valid) gx[(size_t)b * sh.I + i] = res;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward w.r.t. the weights, atomic variant: gw_t zero-filled by the host
+// wrapper, then one 256-byte-contiguous global_atomic_add_f32 wave-instruction
+// per (row, input, node, out-chunk).
+// ---------------------------------------------------------------------------
+template <int N, int RW>
+__global__ __launch_bounds__(256) void pp_bwd_weight_atomic_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ gy,
+                                                                   float* __restrict__ gwt,
+                                                                   PPShape sh, BasisTab tab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  if (row0 >= sh.B) return;
+  const int o = blockIdx.y * 64 + lane;
+  const bool o_ok = o < sh.O;
+  const int oc = o_ok ? o : sh.O - 1;
+
+  float g[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int b = row0 + r;
+    g[r] = (b < sh.B && o_ok) ? gy[(size_t)b * sh.O + oc] * sh.out_scale : 0.0f;
+  }
+  for (int i0 = 0; i0 < sh.I; i0 += 64) {
+    const int i = i0 + lane;
+    int koff[RW];
+    float l[RW][N];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int b = min(row0 + r, sh.B - 1);
+      const bool valid = i < sh.I;
+      const float xv = valid ? x[(size_t)b * sh.I + i] : 0.0f;
+      const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
+      const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
+      pp_lagrange<N>(xi, tab, l[r]);
+      koff[r] = (valid ? i : 0) * sh.K + s * sh.stride;
+    }
+    const int cnt = min(64, sh.I - i0);
+    for (int ii = 0; ii < cnt; ++ii) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= sh.B) continue;  // wave-uniform
+        const int ko = pp_readlane_i(koff[r], ii);
+        float* p = gwt + (size_t)ko * sh.O + oc;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float lj = pp_readlane_f(l[r][j], ii);
+          if (o_ok) atomicAdd(p + (size_t)j * sh.O, lj * g[r]);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dst[c][r] = src[r][c]  (32x32 LDS tiles, +1 padding)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_transpose_kernel(const float* __restrict__ src,
+                                                           float* __restrict__ dst, int rows,
+                                                           int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+// widest vector width V in {4,2,1} with O % V == 0 minimising wave-instructions per row
+int pick_vec(int O) {
+  int best = 1, best_cost = (O + 63) / 64;
+  for (int V : {2, 4}) {
+    if (O % V) continue;
+    int cost = (O / V + 63) / 64;
+    if (cost <= best_cost) { best = V; best_cost = cost; }
+  }
+  return best;
+}
+
+template <int N, int V>
+hipError_t fwd_dispatch_rw(const float* x, const float* wt, float* y, int32_t* seg,
+                           const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  const int nchunk = (sh.O + 64 * V - 1) / (64 * V);
+  // enough waves to fill 256 CUs first; then amortise the per-pair prologue over RW rows
+  const long waves1 = (long)sh.B * nchunk;
+  if (waves1 >= 4L * 4096) {
+    constexpr int RW = 4;
+    dim3 grid((sh.B + 4 * RW - 1) / (4 * RW), nchunk);
+    hipLaunchKernelGGL((pp_fwd_gather_kernel<N, V, RW>), grid, dim3(256), 0, st, x, wt, y, seg, sh,
+                       tab);
+  } else {
+    constexpr int RW = 1;
+    dim3 grid((sh.B + 4 * RW - 1) / (4 * RW), nchunk);
+    hipLaunchKernelGGL((pp_fwd_gather_kernel<N, V, RW>), grid, dim3(256), 0, st, x, wt, y, seg, sh,
+                       tab);
+  }
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t fwd_dispatch_v(const float* x, const float* wt, float* y, int32_t* seg,
+                          const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  switch (pick_vec(sh.O)) {
+    case 4: return fwd_dispatch_rw<N, 4>(x, wt, y, seg, sh, tab, st);
+    case 2: return fwd_dispatch_rw<N, 2>(x, wt, y, seg, sh, tab, st);
+    default: return fwd_dispatch_rw<N, 1>(x, wt, y, seg, sh, tab, st);
+  }
+}
+
+template <int N>
+hipError_t bwdx_dispatch_v(const float* x, const float* gy, const float* wt, float* gx,
+                           const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  dim3 grid((sh.B + 3) / 4);
+  switch (pick_vec(sh.O)) {
+    case 4:
+      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 4>), grid, dim3(256), 0, st, x, gy, wt, gx,
+                         sh, tab);
+      break;
+    case 2:
+      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 2>), grid, dim3(256), 0, st, x, gy, wt, gx,
+                         sh, tab);
+      break;
+    default:
+      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 1>), grid, dim3(256), 0, st, x, gy, wt, gx,
+                         sh, tab);
+  }
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t bwdw_atomic_dispatch(const float* x, const float* gy, float* gwt, const PPShape& sh,
+                                const BasisTab& tab, hipStream_t st) {
+  const int nchunk = (sh.O + 63) / 64;
+  if ((long)sh.B * nchunk >= 4L * 4096) {
+    dim3 grid((sh.B + 15) / 16, nchunk);
+    hipLaunchKernelGGL((pp_bwd_weight_atomic_kernel<N, 4>), grid, dim3(256), 0, st, x, gy, gwt, sh,
+                       tab);
+  } else {
+    dim3 grid((sh.B + 3) / 4, nchunk);
+    hipLaunchKernelGGL((pp_bwd_weight_atomic_kernel<N, 1>), grid, dim3(256), 0, st, x, gy, gwt, sh,
+                       tab);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#define PP_SWITCH_N(n, CALL)          \
+  switch (n) {                        \
+    case 1: return CALL(1);           \
+    case 2: return CALL(2);           \
+    case 3: return CALL(3);           \
+    case 4: return CALL(4);           \
+    case 5: return CALL(5);           \
+    case 6: return CALL(6);           \
+    case 7: return CALL(7);           \
+    case 8: return CALL(8);           \
+    default: return hipErrorInvalidValue; \
+  }
+
+hipError_t pp_launch_segment_ids(const float* x, int32_t* seg, const PPShape& sh, hipStream_t st) {
+  const long total = (long)sh.B * sh.I;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(pp_segment_ids_kernel, dim3(blocks), dim3(256), 0, st, x, seg, total,
+                     sh.length, sh.half, sh.Sf, sh.S);
+  return hipGetLastError();
+}
+
+hipError_t pp_launch_fwd_gather(const float* x, const float* wt, float* y, int32_t* seg,
+                                const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+#define CALL(N) fwd_dispatch_v<N>(x, wt, y, seg, sh, tab, st)
+  PP_SWITCH_N(sh.n, CALL)
+#undef CALL
+}
+
+hipError_t pp_launch_bwd_input_gather(const float* x, const float* gy, const float* wt, float* gx,
+                                      const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  if (sh.n == 1)  // piecewise constant: derivative is identically zero
+    return hipMemsetAsync(gx, 0, (size_t)sh.B * sh.I * sizeof(float), st);
+#define CALL(N) bwdx_dispatch_v<N>(x, gy, wt, gx, sh, tab, st)
+  PP_SWITCH_N(sh.n, CALL)
+#undef CALL
+}
+
+hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* gwt,
+                                       const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(gwt, 0, (size_t)sh.I * sh.K * sh.O * sizeof(float), st);
+  if (e != hipSuccess) return e;
+#define CALL(N) bwdw_atomic_dispatch<N>(x, gy, gwt, sh, tab, st)
+  PP_SWITCH_N(sh.n, CALL)
+#undef CALL
+}
+
+hipError_t pp_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(pp_transpose_kernel, grid, dim3(256), 0, st, src, dst, rows, cols);
+  return hipGetLastError();
+}

@@ -1,0 +1,45 @@
+// Internal declarations shared by the translation units of libpphip.so.
+// Not part of the C ABI (that is include/pp_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pp_hip.h"
+
+struct PPShape {
+  int B, I, O, n, S, K, stride, disc;
+  float length, half, Sf, out_scale;
+};
+
+// Node table handed to kernels by value (lands in SGPRs / kernarg).
+struct BasisTab {
+  float X[PP_MAX_N];       // Chebyshev-Lobatto nodes (fp32 values of the caller)
+  float invden[PP_MAX_N];  // 1 / prod_{m!=j} (X_j - X_m)
+};
+
+// ---- gather path (pp_gather.hip) ----
+hipError_t pp_launch_segment_ids(const float* x, int32_t* seg, const PPShape& sh, hipStream_t st);
+hipError_t pp_launch_fwd_gather(const float* x, const float* wt, float* y, int32_t* seg,
+                                const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_bwd_input_gather(const float* x, const float* gy, const float* wt, float* gx,
+                                      const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* gwt,
+                                       const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
+
+// ---- sort + segmented reduce path (pp_sort.hip) ----
+size_t pp_sort_workspace_bytes(const PPShape& sh);
+bool pp_sort_supported(const PPShape& sh);
+hipError_t pp_launch_bwd_weight_sort(const float* x, const float* gy, float* gwt, void* ws,
+                                     const PPShape& sh, const BasisTab& tab, hipStream_t st);
+
+// ---- dense f32-MFMA path (pp_dense.hip) ----
+bool pp_dense_supported(const PPShape& sh);
+size_t pp_dense_bwd_weight_workspace_bytes(const PPShape& sh);
+hipError_t pp_launch_fwd_dense(const float* x, const float* wt, float* y, int32_t* seg,
+                               const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const float* wt, float* gx,
+                                     const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gwt, void* ws,
+                                      const PPShape& sh, const BasisTab& tab, hipStream_t st);

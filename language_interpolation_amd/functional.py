@@ -1,0 +1,201 @@
+"""torch.autograd.Function over the C ABI of libpphip.so.
+
+Host side of the hot path: it validates tensors, hands raw device pointers and
+the current HIP stream to the library, and owns nothing else.  The forward
+saves only (x, w): segment ids, local coordinates and basis values are
+recomputed in the backward kernels instead of keeping the reference's
+[B, I, O, n] gathered tensor alive.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def chebyshev_lobatto(n: int, length: float = 2.0) -> torch.Tensor:
+    """fp32 nodes -cos(pi k/(n-1)) * length/2, computed in torch fp32 like the
+    upstream layer does (so the middle node of an odd n is ~4.4e-8, not 0)."""
+    if n == 1:
+        return torch.zeros(1, dtype=torch.float32)
+    k = torch.arange(0, n)
+    ans = -torch.cos(k * math.pi / (n - 1))
+    ans = torch.where(torch.abs(ans) < 1e-15, 0 * ans, ans)
+    return ((length / 2.0) * ans).to(torch.float32)
+
+
+def num_weights(n: int, segments: int, discontinuous: bool) -> int:
+    return n * segments if discontinuous else (n - 1) * segments + 1
+
+
+@dataclass(frozen=True)
+class LayerSpec:
+    """Static description of one layer, hashable so it can ride through autograd."""
+
+    n: int
+    segments: int
+    discontinuous: bool
+    length: float = 2.0
+    out_scale: float = 1.0
+    fwd_method: str = "auto"
+    bwd_x_method: str = "auto"
+    bwd_w_method: str = "auto"
+    nodes: Tuple[float, ...] = field(default=())
+
+    def node_array(self):
+        vals = self.nodes if self.nodes else tuple(chebyshev_lobatto(self.n, self.length).tolist())
+        return (ctypes.c_float * self.n)(*vals)
+
+
+def make_spec(n, segments, discontinuous, length=2.0, rescale_output=False, in_features=1,
+              fwd_method="auto", bwd_x_method="auto", bwd_w_method="auto") -> LayerSpec:
+    if n < 1 or n > _lib.PP_MAX_N:
+        raise ValueError(f"n={n}: the HIP kernels support 1 <= n <= {_lib.PP_MAX_N}")
+    if not discontinuous and n < 2:
+        raise ValueError("a continuous piecewise layer needs n >= 2 nodes per segment")
+    return LayerSpec(
+        n=int(n), segments=int(segments), discontinuous=bool(discontinuous), length=float(length),
+        out_scale=(1.0 / in_features) if rescale_output else 1.0,
+        fwd_method=fwd_method, bwd_x_method=bwd_x_method, bwd_w_method=bwd_w_method,
+        nodes=tuple(chebyshev_lobatto(n, length).tolist()),
+    )
+
+
+def _require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the piecewise-polynomial layer runs on MI355X (HIP) only; "
+            "there is no CPU path in this package (oracle/ is test infrastructure, not a fallback)"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def kernel_layout(w: torch.Tensor) -> torch.Tensor:
+    """[I,K,O]-contiguous view (or copy) of a logical [O,I,K] weight."""
+    wt = w.permute(1, 2, 0)
+    return wt if wt.is_contiguous() else wt.contiguous()
+
+
+def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False):
+    """y (and optionally int32 segment ids) for x[B,I], w_t[I,K,O]; no autograd."""
+    lib = _lib.load()
+    _require_gpu(x, "x")
+    _require_gpu(w_t, "w")
+    B, I = x.shape
+    I2, K, O = w_t.shape
+    if I2 != I or K != num_weights(spec.n, spec.segments, spec.discontinuous):
+        raise ValueError(f"weight {tuple(w_t.shape)} does not match x {tuple(x.shape)} / {spec}")
+    y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+    seg = torch.empty(B, I, device=x.device, dtype=torch.int32) if want_seg else None
+    if B == 0:
+        return y, seg
+    with torch.cuda.device(x.device):
+        rc = lib.pp_forward_f32(
+            _ptr(x), _ptr(w_t), _ptr(y), _ptr(seg), B, I, O, spec.n, spec.segments,
+            int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale,
+            _lib.FWD_METHODS[spec.fwd_method], _stream(x.device))
+    _lib.check(rc, "pp_forward_f32")
+    return y, seg
+
+
+def backward_input_raw(x, gy, w_t, spec: LayerSpec):
+    lib = _lib.load()
+    B, I = x.shape
+    O = w_t.shape[2]
+    gx = torch.empty_like(x)
+    if B == 0:
+        return gx
+    with torch.cuda.device(x.device):
+        rc = lib.pp_backward_input_f32(
+            _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), B, I, O, spec.n, spec.segments,
+            int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale,
+            _lib.BWD_X_METHODS[spec.bwd_x_method], _stream(x.device))
+    _lib.check(rc, "pp_backward_input_f32")
+    return gx
+
+
+def backward_weight_raw(x, gy, w_shape_t, spec: LayerSpec):
+    """gw_t[I,K,O] (kernel layout), dense."""
+    lib = _lib.load()
+    B, I = x.shape
+    I2, K, O = w_shape_t
+    gw_t = torch.empty(I2, K, O, device=x.device, dtype=torch.float32)
+    if B == 0:
+        return gw_t.zero_()
+    method = _lib.BWD_W_METHODS[spec.bwd_w_method]
+    nbytes = lib.pp_workspace_bytes(B, I, O, spec.n, spec.segments, int(spec.discontinuous), method)
+    ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8) if nbytes else None
+    with torch.cuda.device(x.device):
+        rc = lib.pp_backward_weight_f32(
+            _ptr(x), _ptr(gy), _ptr(gw_t), _ptr(ws), nbytes, B, I, O, spec.n, spec.segments,
+            int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale, method,
+            _stream(x.device))
+    _lib.check(rc, "pp_backward_weight_f32")
+    return gw_t
+
+
+def segment_ids(x: torch.Tensor, segments: int, length: float = 2.0) -> torch.Tensor:
+    """int32 segment ids on the GPU (A1 of SURVEY.md 8a)."""
+    lib = _lib.load()
+    _require_gpu(x, "x")
+    x = x.contiguous()
+    seg = torch.empty(x.shape, device=x.device, dtype=torch.int32)
+    if x.numel() == 0:
+        return seg
+    with torch.cuda.device(x.device):
+        rc = lib.pp_segment_ids_f32(_ptr(x), _ptr(seg), x.numel(), 1, segments, length,
+                                    _stream(x.device))
+    _lib.check(rc, "pp_segment_ids_f32")
+    return seg
+
+
+class PiecewisePolyFunction(torch.autograd.Function):
+    """y = piecewise_poly(x[B,I], w[O,I,K]) with hand-written HIP forward/backward."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, w: torch.Tensor, spec: LayerSpec):
+        if x.dim() != 2:
+            raise ValueError(
+                f"piecewise layer forward is 2-D only, got {tuple(x.shape)} (use reshape_apply)")
+        _require_gpu(x, "x")
+        _require_gpu(w, "w")
+        x = x.contiguous()
+        w_t = kernel_layout(w.detach())
+        y, _ = forward_raw(x, w_t, spec)
+        ctx.spec = spec
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        x, w = ctx.saved_tensors
+        spec = ctx.spec
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        w_t = kernel_layout(w.detach())
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = backward_input_raw(x, gy, w_t, spec)
+        if ctx.needs_input_grad[1]:
+            gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec)
+            gw = gw_t.permute(2, 0, 1)  # logical [O,I,K]; same strides as the module's parameter
+        return gx, gw, None
+
+
+def piecewise_poly(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> torch.Tensor:
+    return PiecewisePolyFunction.apply(x, w, spec)

@@ -1,0 +1,109 @@
+"""`HighOrderMLP` / `LowOrderMLP` with the constructor the reference calls
+(/root/reference/language_interpolation/networks.py:866-882, :812-820;
+state_space_network.py:186-196; tests/test_utils.py:9-20).
+
+Sequential ordering (pinned by
+tests/test_dataset_from_representation.py:67-70 of the reference):
+    [PP_in, (norm, [non_linearity], PP_hidden) * hidden_layers, norm, [non_linearity], PP_out]
+`hidden_layers=0` still yields two polynomial layers (in -> hidden_width -> out).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch.nn as nn
+from torch import Tensor
+
+from .layers import high_order_fc_layers
+
+
+class HighOrderMLP(nn.Module):
+    def __init__(
+        self,
+        layer_type: str,
+        n: int,
+        in_width: int,
+        out_width: int,
+        hidden_layers: int,
+        hidden_width: int,
+        scale: float = 2.0,
+        n_in: Optional[int] = None,
+        n_out: Optional[int] = None,
+        n_hidden: Optional[int] = None,
+        rescale_output: bool = False,
+        periodicity: Optional[float] = None,
+        non_linearity: Optional[nn.Module] = None,
+        in_segments: Optional[int] = None,
+        out_segments: Optional[int] = None,
+        hidden_segments: Optional[int] = None,
+        normalization: Optional[Callable[[], nn.Module]] = None,
+        resnet: bool = False,
+        device=None,
+        layer_type_in: Optional[str] = None,
+    ) -> None:
+        super().__init__()
+        if resnet:
+            raise ValueError("resnet=True is outside the hot path (no reference call site uses it)")
+        n_in = n_in or n
+        n_hidden = n_hidden or n
+        n_out = n_out or n
+        common = dict(rescale_output=rescale_output, scale=scale, periodicity=periodicity,
+                      device=device)
+        layer_list = [
+            high_order_fc_layers(layer_type=layer_type_in or layer_type, n=n_in,
+                                 in_features=in_width, out_features=hidden_width,
+                                 segments=in_segments, **common)
+        ]
+        for _ in range(hidden_layers):
+            if normalization is not None:
+                layer_list.append(normalization())
+            if non_linearity is not None:
+                layer_list.append(non_linearity)
+            layer_list.append(
+                high_order_fc_layers(layer_type=layer_type, n=n_hidden, in_features=hidden_width,
+                                     out_features=hidden_width, segments=hidden_segments, **common))
+        if normalization is not None:
+            layer_list.append(normalization())
+        if non_linearity is not None:
+            layer_list.append(non_linearity)
+        layer_list.append(
+            high_order_fc_layers(layer_type=layer_type, n=n_out, in_features=hidden_width,
+                                 out_features=out_width, segments=out_segments, **common))
+        self.model = nn.Sequential(*layer_list)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.model(x)
+
+
+class LowOrderMLP(nn.Module):
+    """Linear(+norm)+non-linearity stack used below the polynomial input layer of
+    `net=large_standard` (networks.py:812-820).  GEMM territory: plain
+    `torch.nn.Linear` (rocBLAS/hipBLASLt), deliberately not re-implemented."""
+
+    def __init__(
+        self,
+        in_width: int,
+        out_width: int,
+        hidden_layers: int,
+        hidden_width: int,
+        non_linearity: Optional[nn.Module] = None,
+        normalization: Optional[Callable[[], nn.Module]] = None,
+        device=None,
+    ) -> None:
+        super().__init__()
+        layer_list = [nn.Linear(in_width, hidden_width, device=device)]
+        for _ in range(hidden_layers):
+            if normalization is not None:
+                layer_list.append(normalization())
+            if non_linearity is not None:
+                layer_list.append(non_linearity)
+            layer_list.append(nn.Linear(hidden_width, hidden_width, device=device))
+        if normalization is not None:
+            layer_list.append(normalization())
+        if non_linearity is not None:
+            layer_list.append(non_linearity)
+        layer_list.append(nn.Linear(hidden_width, out_width, device=device))
+        self.model = nn.Sequential(*layer_list)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.model(x)

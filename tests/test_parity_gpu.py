@@ -1,0 +1,216 @@
+"""GPU parity: HIP kernels (through the C ABI of libpphip.so) vs the CPU oracle.
+
+Bar (north_star): segment ids bit-exact; fp32 outputs and gradients within 1e-5
+relative (max-norm per tensor) of the fp64 evaluation of the reference function.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pp_testlib import TOL, make_inputs, oracle_all, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pp_golden.npz")
+
+
+def _pf():
+    from language_interpolation_amd import functional as PF
+    return PF
+
+
+def hip_all(x, w, gy, n, S, disc, fwd="auto", bwd_x="auto", bwd_w="auto", **kw):
+    PF = _pf()
+    dev = torch.device("cuda:0")
+    spec = PF.make_spec(n, S, disc, fwd_method=fwd, bwd_x_method=bwd_x, bwd_w_method=bwd_w,
+                        in_features=x.shape[1], **kw)
+    xd, gyd = x.to(dev), gy.to(dev)
+    w_t = w.to(dev).permute(1, 2, 0).contiguous()
+    y, seg = PF.forward_raw(xd, w_t, spec, want_seg=True)
+    gx = PF.backward_input_raw(xd, gyd, w_t, spec)
+    gw_t = PF.backward_weight_raw(xd, gyd, tuple(w_t.shape), spec)
+    torch.cuda.synchronize()
+    return {"y": y.cpu(), "seg": seg.cpu(), "gx": gx.cpu(), "gw": gw_t.permute(2, 0, 1).cpu()}
+
+
+def check(got, ref, what):
+    assert torch.equal(got["seg"].long(), ref["seg"].long()), f"{what}: segment ids differ"
+    for key in ("y", "gx", "gw"):
+        r = ref[key]
+        if r.abs().max() == 0:
+            assert got[key].abs().max() == 0, (what, key)
+        else:
+            e = rel_err(got[key], r)
+            assert e <= TOL, f"{what}: {key} rel err {e:.3e}"
+
+
+# (disc, n, S, I, O, B, dist)
+CASES = [
+    (False, 2, 128, 16, 250, 257, "char"),      # cfg1/cfg2 input layer
+    (False, 2, 128, 16, 200, 1000, "char"),     # cfg1 L0 at B=1000
+    (True, 2, 128, 16, 1000, 256, "char"),      # cfg4 input layer
+    (True, 1, 150, 200, 200, 300, "normal"),    # cfg3 hidden
+    (True, 2, 150, 200, 200, 128, "normal"),    # cfg3 hidden with the n_hidden quirk
+    (True, 1, 150, 200, 128, 300, "normal"),    # cfg3 output
+    (False, 3, 2, 250, 250, 256, "normal"),     # cfg2 hidden
+    (False, 3, 2, 250, 128, 256, "normal"),     # cfg2 output
+    (False, 2, 2, 200, 200, 1000, "normal"),    # cfg1 hidden
+    (False, 2, 2, 200, 128, 1000, "normal"),    # cfg1 output
+    (False, 3, 2, 64, 256, 240, "normal"),      # cfg5 in_proj L1
+    (False, 3, 2, 256, 256, 240, "normal"),     # cfg5 in_proj L2
+    (False, 3, 2, 128, 68, 240, "normal"),      # cfg5 x_proj
+    (False, 3, 2, 4, 128, 240, "normal"),       # cfg5 dt_proj
+    (False, 3, 2, 128, 64, 240, "normal"),      # cfg5 out_proj
+    (True, 2, 8, 10, 10, 82, "uniform"),        # net=small defaults
+    (False, 5, 2, 10, 5, 35, "uniform"),        # tests/test_utils.py shapes
+    (False, 5, 2, 5, 11, 35, "uniform"),
+    (True, 8, 3, 7, 3, 5, "uniform"),           # max n
+    (False, 4, 5, 65, 1, 3, "edges"),           # O=1, I just over one wave
+    (True, 3, 7, 130, 257, 9, "edges"),         # ragged everything
+    (False, 2, 2, 1, 1, 1, "normal"),           # minimum sizes
+    (True, 1, 1, 3, 5, 17, "normal"),           # one segment, piecewise constant
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_auto_methods_match_oracle(case):
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=1)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc), ref, "auto")
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_gather_and_both_scatter_variants(case):
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=2)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc, "gather", "gather", "atomic"), ref, "gather/atomic")
+    check(hip_all(x, w, gy, n, S, disc, "gather", "gather", "sort"), ref, "gather/sort")
+
+
+def test_golden_vectors():
+    z = np.load(GOLDEN, allow_pickle=False)
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        disc, n, S, I, O, B = (int(v) for v in z[name + "/meta"])
+        x, w, gy = (torch.from_numpy(z[f"{name}/{k}"]) for k in ("x", "w", "gy"))
+        ref = {k: torch.from_numpy(z[f"{name}/{k}"]) for k in ("y", "seg", "gx", "gw")}
+        for bw in ("atomic", "sort", "auto"):
+            check(hip_all(x, w, gy, n, S, bool(disc), bwd_w=bw), ref, f"{name}/{bw}")
+
+
+@pytest.mark.parametrize("S", [2, 8, 128, 150, 1000])
+def test_segment_ids_bit_exact_sweep(S):
+    """P8 of SURVEY 8c: every fp32 value within a few ulp of each boundary, plus
+    out-of-range and non-finite inputs."""
+    from oracle import pp_oracle as po
+    PF = _pf()
+    xs = []
+    for m in range(S + 1):
+        v = np.float32(-1.0 + 2.0 * m / S)
+        for _ in range(6):
+            v = np.nextafter(v, np.float32(-3.0))
+        for _ in range(13):
+            xs.append(v)
+            v = np.nextafter(v, np.float32(3.0))
+    xs += [-3.0, 3.0, -1e9, 1e9, 0.0, -0.0, 1e30, -1e30, np.inf, -np.inf, np.nan, 1e-45]
+    x = torch.tensor(np.asarray(xs, dtype=np.float32)).reshape(-1, 1)
+    want = po.segment_ids(x, S).flatten()
+    got = PF.segment_ids(x.cuda(), S).cpu().flatten().long()
+    assert torch.equal(got, want)
+
+
+def test_character_grid_is_exact():
+    """P5: x=(c-63.5)/64 with S=128 gives s=c and xi=0, so y is a pure table lookup."""
+    from oracle import pp_oracle as po
+    PF = _pf()
+    c = torch.arange(128).reshape(-1, 1)
+    x = po.ascii_to_float(c)
+    w = torch.randn(5, 1, 129)
+    spec = PF.make_spec(2, 128, False)
+    y, seg = PF.forward_raw(x.cuda(), w.cuda().permute(1, 2, 0).contiguous(), spec, want_seg=True)
+    assert torch.equal(seg.cpu().flatten().long(), c.flatten())
+    want = 0.5 * (w[:, 0, :128] + w[:, 0, 1:]).t()
+    assert torch.allclose(y.cpu(), want, atol=1e-6)
+
+
+def test_length_rescale_and_properties():
+    PF = _pf()
+    # non-default length and rescale_output against the oracle
+    disc, n, S, I, O, B = False, 3, 4, 12, 9, 40
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=3)
+    for length in (2.0, 3.0):
+        ref = oracle_all(x, w, gy, n, S, disc, length=length, rescale_output=True)
+        for bw in ("atomic", "sort"):
+            got = hip_all(x, w, gy, n, S, disc, bwd_w=bw, length=length, rescale_output=True)
+            check(got, ref, f"length={length}/{bw}")
+    # P1 partition of unity at full size: w == 1 -> y == I wherever x is
+    B, I, O = 4096, 200, 200
+    x = (torch.randn(B, I) * 2).cuda()
+    for disc, n, S in ((True, 1, 150), (False, 3, 2), (True, 2, 128)):
+        K = PF.num_weights(n, S, disc)
+        spec = PF.make_spec(n, S, disc)
+        y, _ = PF.forward_raw(x, torch.ones(I, K, O, device="cuda"), spec)
+        assert (y - I).abs().max().item() <= 1e-5 * I * 40
+
+
+def test_linearity_and_scatter_consistency_at_full_size():
+    """Size-independent properties at a BASELINE-sized shape: forward is linear in
+    w; <gy, y(w)> == <gw, w> (the weight gradient is the adjoint of the forward)."""
+    PF = _pf()
+    for disc, n, S, I, O, B, dist in ((True, 1, 150, 200, 200, 16384, "normal"),
+                                      (True, 2, 128, 16, 1000, 1024, "char"),
+                                      (False, 3, 2, 250, 250, 8192, "normal")):
+        x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=4)
+        x, gy = x.cuda(), gy.cuda()
+        w_t = w.cuda().permute(1, 2, 0).contiguous()
+        spec = PF.make_spec(n, S, disc)
+        y1, _ = PF.forward_raw(x, w_t, spec)
+        y2, _ = PF.forward_raw(x, 2.5 * w_t, spec)
+        assert rel_err(y2, 2.5 * y1) <= 2e-6
+        lhs = (gy.double() * y1.double()).sum().item()
+        for bw in ("atomic", "sort"):
+            spec_b = PF.make_spec(n, S, disc, bwd_w_method=bw)
+            gw_t = PF.backward_weight_raw(x, gy, tuple(w_t.shape), spec_b)
+            rhs = (gw_t.double() * w_t.double()).sum().item()
+            scale = (gy.double().abs() * y1.double().abs()).sum().item()
+            assert abs(lhs - rhs) <= 1e-6 * scale, (bw, lhs, rhs)
+
+
+def test_module_autograd_path_and_empty_batch():
+    import language_interpolation_amd as L
+    from oracle import pp_oracle as po
+    torch.manual_seed(0)
+    net = L.HighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=12, hidden_layers=1,
+                         hidden_width=20, in_segments=128, out_segments=2, hidden_segments=2,
+                         n_in=2, normalization=L.LazyLayerNormLastDim, device="cuda")
+    ora = po.OracleHighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=12,
+                                hidden_layers=1, hidden_width=20, in_segments=128, out_segments=2,
+                                hidden_segments=2, n_in=2,
+                                normalization=po.OracleLazyLayerNormLastDim)
+    ora = ora.double()
+    with torch.no_grad():
+        for a, b in zip(ora.parameters(), net.parameters()):
+            a.copy_(b.detach().cpu().double())
+    x = (torch.rand(33, 16) * 2 - 1)
+    gy = torch.randn(33, 12)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    y.backward(gy.cuda())
+    xo = x.double().requires_grad_(True)
+    # fp64 oracle network (its segment ids come from the fp32 cast inside segment_ids)
+    yo = ora(xo)
+    yo.backward(gy.double())
+    assert rel_err(y.detach(), yo.detach()) <= 5e-5
+    assert rel_err(xg.grad, xo.grad) <= 5e-4  # through two LayerNorms
+    for a, b in zip(ora.parameters(), net.parameters()):
+        assert b.grad.shape == b.shape and b.grad.stride() == b.stride()
+        assert rel_err(b.grad, a.grad) <= 5e-4
+    # ragged / empty input
+    empty = net(torch.empty(0, 16, device="cuda"))
+    assert empty.shape == (0, 12)
+    # reshape_apply on [b, l, d]
+    out = L.reshape_apply(torch.rand(7, 5, 16, device="cuda") * 2 - 1, net)
+    assert out.shape == (7, 5, 12)
