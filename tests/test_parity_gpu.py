@@ -91,6 +91,28 @@ def test_gather_and_both_scatter_variants(case):
     check(hip_all(x, w, gy, n, S, disc, "gather", "gather", "sort"), ref, "gather/sort")
 
 
+DENSE_CASES = [c for c in CASES if 2 <= (c[1] * c[2] if c[0] else (c[1] - 1) * c[2] + 1) <= 8] + [
+    (True, 2, 4, 40, 70, 100, "edges"),     # K=8, non power-of-two free
+    (False, 2, 3, 33, 31, 77, "normal"),    # S=3: inexact-width branch
+    (True, 1, 8, 64, 64, 300, "normal"),
+    (False, 4, 2, 100, 96, 130, "normal"),  # K=7
+    (False, 3, 2, 250, 250, 4096, "normal"),  # several row chunks in the weight gradient
+]
+
+
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_dense_mfma_methods(case):
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=5)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc, "dense", "dense", "dense"), ref, "dense")
+    if dist == "normal" and not disc:
+        ref3 = oracle_all(x, w, gy, n, S, disc, length=4.0, rescale_output=True)
+        got3 = hip_all(x, w, gy, n, S, disc, "dense", "dense", "dense", length=4.0,
+                       rescale_output=True)
+        check(got3, ref3, "dense/length4")
+
+
 def test_golden_vectors():
     z = np.load(GOLDEN, allow_pickle=False)
     for name in sorted({k.split("/")[0] for k in z.files}):
@@ -99,6 +121,10 @@ def test_golden_vectors():
         ref = {k: torch.from_numpy(z[f"{name}/{k}"]) for k in ("y", "seg", "gx", "gw")}
         for bw in ("atomic", "sort", "auto"):
             check(hip_all(x, w, gy, n, S, bool(disc), bwd_w=bw), ref, f"{name}/{bw}")
+        K = n * S if disc else (n - 1) * S + 1
+        if K <= 8:
+            check(hip_all(x, w, gy, n, S, bool(disc), "dense", "dense", "dense"), ref,
+                  f"{name}/dense")
 
 
 @pytest.mark.parametrize("S", [2, 8, 128, 150, 1000])
