@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the gradient all-reduce that bench.py / the DDP harness
+use for N > 1 (the layers themselves are HIP-only, so the replicas here are small
+torch modules with the same parameter layout trick: a permuted, non-contiguous leaf)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class PermutedLinear(nn.Module):
+    """y = x @ w.sum(-1).T with w stored like the polynomial layers' parameter:
+    logical [O, I, K], physical [I, K, O]."""
+
+    def __init__(self, I, O, K):
+        super().__init__()
+        self.w = nn.Parameter(torch.randn(I, K, O).permute(2, 0, 1))
+
+    def forward(self, x):
+        return x @ self.w.sum(-1).t()
+
+
+def build():
+    torch.manual_seed(0)
+    return nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
+
+
+def data(rank):
+    g = torch.Generator().manual_seed(10 + rank)
+    return torch.randn(8, 6, generator=g), torch.randn(8, 5, generator=g)
+
+
+def worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from language_interpolation_amd.parallel import GradAllReducer, broadcast_parameters
+
+    torch.manual_seed(123 + rank)  # replicas start different; broadcast must fix that
+    net = nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
+    broadcast_parameters(net)
+    red = GradAllReducer(net.parameters(), small_numel=4096)
+    for _ in range(2):  # two steps: state must reset between them
+        for p in net.parameters():
+            p.grad = None
+        x, t = data(rank)
+        ((net(x) - t) ** 2).sum().backward()
+        red.finish()
+    if rank == 0:
+        torch.save({"grads": [p.grad.clone() for p in net.parameters()],
+                    "params": [p.detach().clone() for p in net.parameters()],
+                    "strides": [p.grad.stride() for p in net.parameters()]}, out)
+    dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_grad_allreduce_matches_mean_of_per_rank_grads(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(worker, args=(2, free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    # single-process reference: same start weights as rank 0 (seed 123), mean of both ranks' grads
+    torch.manual_seed(123)
+    net = nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
+    for a, b in zip(net.parameters(), got["params"]):
+        assert torch.equal(a.detach(), b)
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(2):
+        for p in net.parameters():
+            p.grad = None
+        x, t = data(rank)
+        ((net(x) - t) ** 2).sum().backward()
+        for acc, p in zip(want, net.parameters()):
+            acc += p.grad / 2
+    for g, w_, st, p in zip(got["grads"], want, got["strides"], net.parameters()):
+        assert torch.allclose(g, w_, rtol=1e-5, atol=1e-6)
+        assert tuple(st) == tuple(p.stride())  # layout of the permuted leaf is kept
