@@ -4,12 +4,17 @@
 //
 // Rows are bucketed per (input i, segment s) with a two-level counting sort
 // (LDS histograms per block -> per-bucket chunk prefix -> scan of bucket totals
-// -> placement), which leaves, per bucket, a contiguous list of (row id, xi).
-// One wavefront then owns one OUTPUT row (i,k) x one 64*V-wide out chunk, walks
-// the one bucket (discontinuous) or two adjacent buckets (continuous layers share
-// the node between neighbouring segments) that feed it, and writes the row once:
-// a dense result with untouched rows written as 0, so no zero-fill pass and no
-// float atomics.
+// -> placement), which leaves the (row id, xi, bucket id) records sorted by bucket.
+// The sorted record array is then cut into equal units of E records; one
+// wavefront owns one unit x one 64*V-wide out chunk, so every wave does the same
+// amount of gather work however skewed the buckets are (text: the space
+// character's bucket holds ~18 % of all rows).  Walking its records, a wave keeps
+// the n node accumulators of the current bucket in registers (each gy row is read
+// ONCE for all n nodes) and flushes them when the bucket id changes: with a plain
+// store when the bucket lies wholly inside the unit and its rows are exclusive
+// (discontinuous layers), else with float atomics into the zero-filled gw
+// (continuous layers share a node between neighbouring segments; long buckets
+// span units).  Atomic traffic is therefore O(units + buckets) rows, not O(B*I).
 //
 // Replaces autograd's index_put_(accumulate=True) scatter into w.grad
 // (loss.backward() at networks.py:164-165 of the reference).
@@ -25,8 +30,12 @@ struct SortPlan {
   int RC;      // rows per chunk
   int nrc;     // row chunks
   int NB;      // buckets = I*S
-  size_t off_counts, off_totals, off_bucket, off_perm_b, off_perm_xi, bytes;
+  int E;       // records per reduce unit
+  int nunit;   // reduce units
+  size_t off_counts, off_totals, off_bucket, off_perm_b, off_perm_xi, off_perm_bkt, bytes;
 };
+
+int pick_vec(int O);
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
@@ -37,15 +46,25 @@ SortPlan make_plan(const PPShape& sh) {
   while (cg > 1 && cg / 2 >= sh.I) cg >>= 1;              // no wider than the row
   p.CG = cg;
   p.ncg = (sh.I + cg - 1) / cg;
-  p.RC = sh.B <= 8192 ? 256 : 1024;
+  const int nrc_target = std::max(1, 256 / p.ncg);
+  p.RC = std::max(128, (((sh.B + nrc_target - 1) / nrc_target) + 63) & ~63);
   p.nrc = (sh.B + p.RC - 1) / p.RC;
   p.NB = sh.I * sh.S;
+  {
+    const int V = pick_vec(sh.O);
+    const long nchunk = (sh.O + 64 * V - 1) / (64 * V);
+    const long total = (long)sh.B * sh.I;
+    long e = (total * nchunk / 8192 + 63) & ~63L;  // aim for ~8192 waves
+    p.E = (int)std::max<long>(64, std::min<long>(512, e));
+    p.nunit = (int)((total + p.E - 1) / p.E);
+  }
   size_t o = 0;
   p.off_counts = o;  o += align16((size_t)p.nrc * p.NB * sizeof(int));
   p.off_totals = o;  o += align16((size_t)p.NB * sizeof(int));
   p.off_bucket = o;  o += align16((size_t)(p.NB + 1) * sizeof(int));
   p.off_perm_b = o;  o += align16((size_t)sh.B * sh.I * sizeof(int));
   p.off_perm_xi = o; o += align16((size_t)sh.B * sh.I * sizeof(float));
+  p.off_perm_bkt = o; o += align16((size_t)sh.B * sh.I * sizeof(int));
   p.bytes = o;
   return p;
 }
@@ -57,7 +76,8 @@ __global__ __launch_bounds__(256) void pp_sort_pass_kernel(const float* __restri
                                                            int* __restrict__ counts,
                                                            const int* __restrict__ bucket_off,
                                                            int* __restrict__ perm_b,
-                                                           float* __restrict__ perm_xi, PPShape sh,
+                                                           float* __restrict__ perm_xi,
+                                                           int* __restrict__ perm_bkt, PPShape sh,
                                                            int CG, int RC, int NB) {
   extern __shared__ int hist[];  // CG*S
   const int t = threadIdx.x;
@@ -84,6 +104,7 @@ __global__ __launch_bounds__(256) void pp_sort_pass_kernel(const float* __restri
         const int pos = atomicAdd(&hist[c * sh.S + s], 1);
         perm_b[pos] = b;
         perm_xi[pos] = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
+        perm_bkt[pos] = (col0 + c) * sh.S + s;
       } else {
         atomicAdd(&hist[c * sh.S + s], 1);
       }
@@ -136,60 +157,94 @@ __global__ __launch_bounds__(1024) void pp_sort_scan_kernel(const int* __restric
   if (t == 1023) bucket_off[NB] = sums[1023];
 }
 
-// K5: segmented reduce. One wave per (output row (i,k), out chunk).
+// K5: balanced segmented reduce.  One wave per (unit of E sorted records, out chunk).
 template <int N, int V>
-__global__ __launch_bounds__(256) void pp_bwd_weight_reduce_kernel(
+__global__ __launch_bounds__(256) void pp_bwd_weight_segreduce_kernel(
     const float* __restrict__ gy, float* __restrict__ gwt, const int* __restrict__ bucket_off,
-    const int* __restrict__ perm_b, const float* __restrict__ perm_xi, PPShape sh, BasisTab tab) {
+    const int* __restrict__ perm_b, const float* __restrict__ perm_xi,
+    const int* __restrict__ perm_bkt, PPShape sh, BasisTab tab, int E, int total) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= sh.I * sh.K) return;
-  const int i = row / sh.K;
-  const int k = row - i * sh.K;
+  const int unit = blockIdx.x * 4 + wave;
+  const int e_beg = unit * E;
+  if (e_beg >= total) return;
+  const int e_end = min(total, e_beg + E);
   const int o = (blockIdx.y * 64 + lane) * V;
   const bool o_ok = o < sh.O;
   const int oc = o_ok ? o : sh.O - V;
 
-  float acc[V];
+  float acc[N][V];
 #pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = 0.0f;
-
-  const int s_hi = min(sh.S - 1, k / sh.stride);
-  const int num = k - (sh.n - 1);
-  const int s_lo = num <= 0 ? 0 : (num + sh.stride - 1) / sh.stride;
-  for (int s = s_lo; s <= s_hi; ++s) {
-    const int j = k - s * sh.stride;  // 0 <= j <= n-1
-    const int beg = bucket_off[i * sh.S + s];
-    const int end = bucket_off[i * sh.S + s + 1];
-    for (int e0 = beg; e0 < end; e0 += 64) {
-      const int e = e0 + lane;
-      const bool valid = e < end;
-      const int bb = valid ? perm_b[e] : 0;
-      const float xi = valid ? perm_xi[e] : 0.0f;
-      float l[N];
-      pp_lagrange<N>(xi, tab, l);
-      float lj = l[0];
+  for (int j = 0; j < N; ++j)
 #pragma unroll
-      for (int m = 1; m < N; ++m) lj = (m == j) ? l[m] : lj;
-      const int cnt = min(64, end - e0);
+    for (int v = 0; v < V; ++v) acc[j][v] = 0.0f;
+  int cur = -1;
 
-      for (int ee = 0; ee < cnt; ++ee) {
+  auto flush = [&]() {
+    if (cur < 0) return;
+    const int i = cur / sh.S;
+    const int s = cur - i * sh.S;
+    const size_t row0 = (size_t)i * sh.K + (size_t)s * sh.stride;
+    // exclusive rows + bucket wholly inside this unit -> nobody else writes them
+    const bool excl = sh.disc && bucket_off[cur] >= e_beg && bucket_off[cur + 1] <= e_end;
+    if (o_ok) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float* p = gwt + (row0 + j) * sh.O + o;
+        if (excl) {
+          PPVec<V> out;
+#pragma unroll
+          for (int v = 0; v < V; ++v) out.v[v] = acc[j][v] * sh.out_scale;
+          out.store(p);
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) atomicAdd(p + v, acc[j][v] * sh.out_scale);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[j][v] = 0.0f;
+  };
+
+  for (int e0 = e_beg; e0 < e_end; e0 += 64) {
+    const int e = e0 + lane;
+    const bool valid = e < e_end;
+    const int bb = valid ? perm_b[e] : 0;
+    const int bk = valid ? perm_bkt[e] : 0;
+    const float xi = valid ? perm_xi[e] : 0.0f;
+    float l[N];
+    pp_lagrange<N>(xi, tab, l);
+    const int cnt = min(64, e_end - e0);
+    for (int g = 0; g < cnt; g += 8) {
+      PPVec<V> rows[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ee = min(g + u, cnt - 1);
         const int b = pp_readlane_i(bb, ee);
-        const float c = pp_readlane_f(lj, ee);
-        PPVec<V> g;
-        g.load(gy + (size_t)b * sh.O + oc);
+        rows[u].load(gy + (size_t)b * sh.O + oc);
+      }
 #pragma unroll
-        for (int v = 0; v < V; ++v) acc[v] = fmaf(c, g.v[v], acc[v]);
+      for (int u = 0; u < 8; ++u) {
+        if (g + u < cnt) {  // wave-uniform
+          const int ee = g + u;
+          const int bke = pp_readlane_i(bk, ee);
+          if (bke != cur) {
+            flush();
+            cur = bke;
+          }
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float c = pp_readlane_f(l[j], ee);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[j][v] = fmaf(c, rows[u].v[v], acc[j][v]);
+          }
+        }
       }
     }
   }
-  if (o_ok) {
-    PPVec<V> out;
-#pragma unroll
-    for (int v = 0; v < V; ++v) out.v[v] = acc[v] * sh.out_scale;
-    out.store(gwt + (size_t)row * sh.O + o);
-  }
+  flush();
 }
 
 int pick_vec(int O) {
@@ -204,23 +259,24 @@ int pick_vec(int O) {
 
 template <int N>
 hipError_t reduce_dispatch(const float* gy, float* gwt, const int* bucket_off, const int* perm_b,
-                           const float* perm_xi, const PPShape& sh, const BasisTab& tab,
-                           hipStream_t st) {
+                           const float* perm_xi, const int* perm_bkt, const SortPlan& pl,
+                           const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const int V = pick_vec(sh.O);
   const int nchunk = (sh.O + 64 * V - 1) / (64 * V);
-  dim3 grid((sh.I * sh.K + 3) / 4, nchunk);
+  const int total = sh.B * sh.I;
+  dim3 grid((pl.nunit + 3) / 4, nchunk);
   switch (V) {
     case 4:
-      hipLaunchKernelGGL((pp_bwd_weight_reduce_kernel<N, 4>), grid, dim3(256), 0, st, gy, gwt,
-                         bucket_off, perm_b, perm_xi, sh, tab);
+      hipLaunchKernelGGL((pp_bwd_weight_segreduce_kernel<N, 4>), grid, dim3(256), 0, st, gy, gwt,
+                         bucket_off, perm_b, perm_xi, perm_bkt, sh, tab, pl.E, total);
       break;
     case 2:
-      hipLaunchKernelGGL((pp_bwd_weight_reduce_kernel<N, 2>), grid, dim3(256), 0, st, gy, gwt,
-                         bucket_off, perm_b, perm_xi, sh, tab);
+      hipLaunchKernelGGL((pp_bwd_weight_segreduce_kernel<N, 2>), grid, dim3(256), 0, st, gy, gwt,
+                         bucket_off, perm_b, perm_xi, perm_bkt, sh, tab, pl.E, total);
       break;
     default:
-      hipLaunchKernelGGL((pp_bwd_weight_reduce_kernel<N, 1>), grid, dim3(256), 0, st, gy, gwt,
-                         bucket_off, perm_b, perm_xi, sh, tab);
+      hipLaunchKernelGGL((pp_bwd_weight_segreduce_kernel<N, 1>), grid, dim3(256), 0, st, gy, gwt,
+                         bucket_off, perm_b, perm_xi, perm_bkt, sh, tab, pl.E, total);
   }
   return hipGetLastError();
 }
@@ -242,27 +298,31 @@ hipError_t pp_launch_bwd_weight_sort(const float* x, const float* gy, float* gwt
   int* bucket_off = reinterpret_cast<int*>(base + p.off_bucket);
   int* perm_b = reinterpret_cast<int*>(base + p.off_perm_b);
   float* perm_xi = reinterpret_cast<float*>(base + p.off_perm_xi);
+  int* perm_bkt = reinterpret_cast<int*>(base + p.off_perm_bkt);
+  hipError_t e = hipMemsetAsync(gwt, 0, (size_t)sh.I * sh.K * sh.O * sizeof(float), st);
+  if (e != hipSuccess) return e;
 
   const dim3 sgrid(p.ncg, p.nrc);
   const size_t lds = (size_t)p.CG * sh.S * sizeof(int);
   hipLaunchKernelGGL((pp_sort_pass_kernel<false>), sgrid, dim3(256), lds, st, x, counts,
-                     (const int*)nullptr, (int*)nullptr, (float*)nullptr, sh, p.CG, p.RC, p.NB);
+                     (const int*)nullptr, (int*)nullptr, (float*)nullptr, (int*)nullptr, sh, p.CG, p.RC,
+                     p.NB);
   hipLaunchKernelGGL(pp_sort_prefix_kernel, dim3((p.NB + 255) / 256), dim3(256), 0, st, counts,
                      totals, p.NB, p.nrc);
   hipLaunchKernelGGL(pp_sort_scan_kernel, dim3(1), dim3(1024), 0, st, totals, bucket_off, p.NB);
   hipLaunchKernelGGL((pp_sort_pass_kernel<true>), sgrid, dim3(256), lds, st, x, counts,
-                     (const int*)bucket_off, perm_b, perm_xi, sh, p.CG, p.RC, p.NB);
-  hipError_t e = hipGetLastError();
+                     (const int*)bucket_off, perm_b, perm_xi, perm_bkt, sh, p.CG, p.RC, p.NB);
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
   switch (sh.n) {
-    case 1: return reduce_dispatch<1>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 2: return reduce_dispatch<2>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 3: return reduce_dispatch<3>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 4: return reduce_dispatch<4>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 5: return reduce_dispatch<5>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 6: return reduce_dispatch<6>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 7: return reduce_dispatch<7>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
-    case 8: return reduce_dispatch<8>(gy, gwt, bucket_off, perm_b, perm_xi, sh, tab, st);
+    case 1: return reduce_dispatch<1>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 2: return reduce_dispatch<2>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 3: return reduce_dispatch<3>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 4: return reduce_dispatch<4>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 5: return reduce_dispatch<5>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 6: return reduce_dispatch<6>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 7: return reduce_dispatch<7>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
+    case 8: return reduce_dispatch<8>(gy, gwt, bucket_off, perm_b, perm_xi, perm_bkt, p, sh, tab, st);
     default: return hipErrorInvalidValue;
   }
 }
