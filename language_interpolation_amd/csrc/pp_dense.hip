@@ -1,17 +1,26 @@
 // Dense path: expanded-basis x weight contraction on the f32-input MFMA
-// (v_mfma_f32_32x32x2_f32, exact fp32 fma chain), for layers whose weight count
-// per (out, in) pair K is small (segments = 2 in every hidden layer of the
-// BASELINE configs), i.e. where n of the K basis columns are nonzero per sample.
+// (v_mfma_f32_32x32x2_f32: an exact fp32 fma chain at the fp32 vector peak), for
+// layers whose weight count per (out, in) pair K is small (segments = 2 in every
+// hidden layer of the BASELINE configs), i.e. where n of the K basis columns are
+// nonzero per sample and the contraction is GEMM-shaped.
 //
-//   forward   y[b,o]      = sum_{i,k} Phi[b,i,k] * w_t[i,k,o]
-//   bwd-input G[b,(i,k)]  = sum_o gy[b,o] * w_t[i,k,o];  gx[b,i] = chain * sum_k Phi'[b,i,k] G[b,i,k]
+//   forward    y[b,o]        = sum_{i,k} Phi[b,i,k] * w_t[i,k,o]
+//   bwd-input  G[b,(i,k)]    = sum_o gy[b,o] * w_t[i,k,o];  gx[b,i] = chain * sum_k Phi'[b,i,k] G[b,i,k]
 //   bwd-weight gw_t[(i,k),o] = sum_b Phi[b,i,k] * gy[b,o]
 //
-// Phi is never materialised: each lane evaluates segment id / local coordinate /
-// Lagrange basis for "its" (row, input) pair in registers (A1-A3 of SURVEY.md 8a)
-// and feeds the K basis columns to K MFMAs as the A operand.  The two k-slots of
-// the 32x32x2 MFMA are two different inputs (forward) or two different rows
+// Phi is never materialised in HBM: lanes evaluate segment id / local coordinate /
+// Lagrange basis for "their" (row, input) pair in registers (A1-A3 of SURVEY.md
+// 8a) and feed the K basis columns to K MFMAs as the A operand.  The two k-slots
+// of the 32x32x2 MFMA are two different inputs (forward) or two different rows
 // (bwd-weight), so no lane computes a basis value it does not use.
+//
+// Only "exact" layers take this path: length and segments powers of two, so that
+// the reference's divisions in A1/A2 are exact multiplications and the segment id
+// / local coordinate stay bit-identical without a single v_div sequence in the
+// MFMA loops.  Everything else goes to the gather path.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pp_device.h"
 
 namespace {
@@ -19,29 +28,23 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DenseCoord {
-  float w2;     // 2/S            (exact when S is a power of two)
-  float inv_w;  // length / (2/S) is NOT folded: xi = length*((x-x_min)*inv_w) - half
-  float inv_len;
-  int exact;    // length and S are powers of two: divisions are exact multiplications
+  float w2;       // 2/S
+  float inv_w;    // S/2
+  float inv_len;  // 1/length
 };
 
+// A1 + A2 with the divisions replaced by their exact reciprocal multiplications.
 __device__ __forceinline__ void dense_seg_xi(float x, const PPShape& sh, const DenseCoord& dc,
-                                             int& s, float& xi, float& dxi_dx) {
-  if (dc.exact) {
-    float t = ((x + sh.half) * dc.inv_len) * sh.Sf;
-    s = 0;
-    if (t > -9.2e18f && t < 9.2e18f) {
-      float tc = fminf(fmaxf(t, -1.0f), sh.Sf);
-      s = (int)tc;
-      s = s < 0 ? 0 : (s > sh.S - 1 ? sh.S - 1 : s);
-    }
-    const float x_min = (float)s * dc.w2 - 1.0f;  // == (s/S)*2-1 exactly
-    xi = sh.length * ((x - x_min) * dc.inv_w) - sh.half;
-    dxi_dx = sh.length * dc.inv_w;
-  } else {
-    s = pp_segment(x, sh.length, sh.half, sh.Sf, sh.S);
-    xi = pp_local_coord(x, s, sh.length, sh.half, sh.Sf, &dxi_dx);
+                                             int& s, float& xi) {
+  const float t = ((x + sh.half) * dc.inv_len) * sh.Sf;
+  s = 0;
+  if (t > -9.2e18f && t < 9.2e18f) {
+    const float tc = fminf(fmaxf(t, -1.0f), sh.Sf);
+    s = (int)tc;
+    s = s < 0 ? 0 : (s > sh.S - 1 ? sh.S - 1 : s);
   }
+  const float x_min = (float)s * dc.w2 - 1.0f;  // == (s/S)*2-1 exactly
+  xi = sh.length * ((x - x_min) * dc.inv_w) - sh.half;
 }
 
 // Phi[k] for k = 0..K-1 from the n active basis values (zeros elsewhere).
@@ -57,16 +60,56 @@ __device__ __forceinline__ void expand_basis(const float (&l)[N], int soff, floa
   }
 }
 
+template <int N, int K>
+__device__ __forceinline__ void phi_of_x(float xv, bool valid, const PPShape& sh,
+                                         const BasisTab& tab, const DenseCoord& dc,
+                                         float (&phi)[K], int& s) {
+  float xi, l[N];
+  dense_seg_xi(xv, sh, dc, s, xi);
+  pp_lagrange<N>(xi, tab, l);
+  if (!valid) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) l[j] = 0.0f;
+  }
+  expand_basis<N, K>(l, s * sh.stride, phi);
+}
+
+// W floats starting at p, fetched as VW-wide pieces (VW in {4,2,1}); p is aligned
+// to VW floats.  Piece m is taken from p + min(m, lim) so that a tile hanging over
+// the end of a row still reads valid memory (masked later).
+template <int W, int VW>
+__device__ __forceinline__ void load_pieces(const float* p, int lim, float (&v)[W]) {
+  if constexpr (W >= 4 && VW == 4) {
+#pragma unroll
+    for (int m = 0; m < W; m += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + min(m, lim));
+      v[m] = t.x; v[m + 1] = t.y; v[m + 2] = t.z; v[m + 3] = t.w;
+    }
+  } else if constexpr (W >= 2 && VW >= 2) {
+#pragma unroll
+    for (int m = 0; m < W; m += 2) {
+      const float2 t = *reinterpret_cast<const float2*>(p + min(m, lim));
+      v[m] = t.x; v[m + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < W; ++m) v[m] = p[min(m, lim)];
+  }
+}
+
 // ---------------------------------------------------------------------------
-// forward: wave tile = 32 rows x (NT*32) outputs, k-slots = two inputs
+// forward: wave tile = 32 rows x (32*NT) outputs; lane (r,h) owns outputs
+// o0 + NT*r .. + NT-1 (one wide load per weight row feeds NT MFMAs) and input
+// 2*pair + h.  Software-pipelined: weights of pair p+1 and x of pair p+2 are in
+// flight, and Phi of pair p+1 is evaluated, while the MFMAs of pair p issue.
 // ---------------------------------------------------------------------------
-template <int N, int K, int NT>
-__global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ wt,
-                                                           float* __restrict__ y,
-                                                           int32_t* __restrict__ seg_out,
-                                                           PPShape sh, BasisTab tab,
-                                                           DenseCoord dc) {
+template <int N, int K, int NT, int VW>
+__device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
+                                               const float* __restrict__ wt,
+                                               float* __restrict__ y,
+                                               int32_t* __restrict__ seg_out, const PPShape& sh,
+                                               const BasisTab& tab, const DenseCoord& dc) {
+  constexpr int vw = VW;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -75,10 +118,8 @@ __global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restri
   const int o0 = blockIdx.y * (32 * NT);
   const int b = min(b0 + r, sh.B - 1);
   const bool write_seg = seg_out != nullptr && blockIdx.y == 0 && (b0 + r) < sh.B;
-
-  int ocol[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) ocol[nt] = min(o0 + nt * 32 + r, sh.O - 1);
+  const int ocl = min(o0 + NT * r, sh.O - vw);  // first column this lane loads (clamped)
+  const int lim = sh.O - vw - ocl;              // largest in-row piece offset
 
   f32x16 acc[NT];
 #pragma unroll
@@ -87,65 +128,115 @@ __global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restri
     for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
 
   const float* xrow = x + (size_t)b * sh.I;
-  for (int ip = 0; ip < sh.I; ip += 2) {
-    const int i = ip + h;
-    const bool valid = i < sh.I;
-    const int ic = valid ? i : sh.I - 1;
-    const float xv = xrow[ic];
-    int s;
-    float xi, dd;
-    dense_seg_xi(xv, sh, dc, s, xi, dd);
-    float l[N], phi[K];
-    pp_lagrange<N>(xi, tab, l);
-    if (!valid) {
+  const int npair = (sh.I + 1) >> 1;
+  const int ilast = sh.I - 1;
+
+  float wc[K][NT], wn[K][NT], phic[K], phin[K];
+  int sc;
+  {
+    const int i = min(h, ilast);
+    phi_of_x<N, K>(xrow[i], h <= ilast, sh, tab, dc, phic, sc);
+    if (write_seg && h <= ilast) seg_out[(size_t)b * sh.I + h] = sc;
+    const float* wrow = wt + (size_t)i * K * sh.O + ocl;
 #pragma unroll
-      for (int j = 0; j < N; ++j) l[j] = 0.0f;
-    }
-    expand_basis<N, K>(l, s * sh.stride, phi);
-    if (write_seg && valid) seg_out[(size_t)b * sh.I + i] = s;
-    const float* wrow = wt + (size_t)ic * K * sh.O;
+    for (int k = 0; k < K; ++k) load_pieces<NT, VW>(wrow + (size_t)k * sh.O, lim, wc[k]);
+  }
+  float x1 = xrow[min(2 + h, ilast)];  // pair 1
+  for (int ip = 0; ip < npair; ++ip) {
+    // prefetch: weights of pair ip+1, x of pair ip+2
+    const int i1 = 2 * (ip + 1) + h;
+    const int i1c = min(i1, ilast);
+    const float* wrow = wt + (size_t)i1c * K * sh.O + ocl;
+#pragma unroll
+    for (int k = 0; k < K; ++k) load_pieces<NT, VW>(wrow + (size_t)k * sh.O, lim, wn[k]);
+    const float x2 = xrow[min(2 * (ip + 2) + h, ilast)];
+    // basis of pair ip+1 (independent of the MFMAs below)
+    int sn;
+    phi_of_x<N, K>(x1, i1 <= ilast, sh, tab, dc, phin, sn);
+    if (write_seg && i1 <= ilast) seg_out[(size_t)b * sh.I + i1] = sn;
+    // MFMAs of pair ip
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phic[k], wc[k][nt], acc[nt], 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+      phic[k] = phin[k];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float bv = wrow[(size_t)k * sh.O + ocol[nt]];
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], bv, acc[nt], 0, 0, 0);
-      }
+      for (int nt = 0; nt < NT; ++nt) wc[k][nt] = wn[k][nt];
     }
+    x1 = x2;
   }
+  // epilogue: lane holds NT consecutive columns for 16 rows
+  const int oc = o0 + NT * r;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = o0 + nt * 32 + r;
-    if (col < sh.O) {
+  for (int q = 0; q < 16; ++q) {
+    const int row = b0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (row < sh.B) {
+      float* yp = y + (size_t)row * sh.O + oc;
+      if constexpr (NT == 4 && VW == 4) {
+        if (oc < sh.O)
+          *reinterpret_cast<float4*>(yp) =
+              make_float4(acc[0][q] * sh.out_scale, acc[1 % NT][q] * sh.out_scale,
+                          acc[2 % NT][q] * sh.out_scale, acc[3 % NT][q] * sh.out_scale);
+      } else if constexpr (VW >= 2) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = b0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (row < sh.B) y[(size_t)row * sh.O + col] = acc[nt][q] * sh.out_scale;
+        for (int m = 0; m < NT; m += 2)
+          if (oc + m < sh.O)
+            *reinterpret_cast<float2*>(yp + m) =
+                make_float2(acc[m][q] * sh.out_scale, acc[(m + 1) % NT][q] * sh.out_scale);
+      } else {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          if (oc + m < sh.O) yp[m] = acc[m][q] * sh.out_scale;
       }
     }
   }
 }
 
+template <int N, int K, int NT>
+__global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ wt,
+                                                           float* __restrict__ y,
+                                                           int32_t* __restrict__ seg_out,
+                                                           PPShape sh, BasisTab tab,
+                                                           DenseCoord dc, int vw) {
+  // vw is wave-uniform: one straight-line body per load width
+  if (NT >= 4 && vw == 4) fwd_dense_body<N, K, NT, (NT >= 4 ? 4 : 2)>(x, wt, y, seg_out, sh, tab, dc);
+  else if (vw >= 2) fwd_dense_body<N, K, NT, 2>(x, wt, y, seg_out, sh, tab, dc);
+  else fwd_dense_body<N, K, NT, 1>(x, wt, y, seg_out, sh, tab, dc);
+}
+
 // ---------------------------------------------------------------------------
-// backward-input: block tile = 128 rows x 32 inputs, wave = 32 rows; K
-// accumulators (one per weight index k); the W tile [K][32 inputs][32 outs] is
-// staged through LDS (row pad 33 -> conflict-free ds_read_b32).
+// backward-input: block tile = 128 rows x 32 inputs (wave = 32 rows), K
+// accumulator tiles (one per weight index k).  The reduction runs over `out` in
+// chunks of 32: the W tile [K][32 inputs][32 outs] of the NEXT chunk is fetched
+// into registers while the current chunk's MFMAs run, then written to the other
+// LDS buffer (one barrier per chunk).  Rows are padded to 36 floats so that the
+// ds_read_b128 of 4 consecutive outs per lane is bank-conflict-free.  Lane (r,h)
+// takes outs 8t+4h..+3 of each group of 8: one 16-byte gy load and K
+// ds_read_b128 feed 4K MFMAs.
 // ---------------------------------------------------------------------------
-template <int N, int K>
-__global__ __launch_bounds__(256) void pp_bwd_input_dense_kernel(const float* __restrict__ x,
-                                                                 const float* __restrict__ gy,
-                                                                 const float* __restrict__ wt,
-                                                                 float* __restrict__ gx,
-                                                                 PPShape sh, BasisTab tab,
-                                                                 DenseCoord dc) {
-  __shared__ float wl[K * 32 * 33];
+constexpr int kWStride = 36;
+
+template <int N, int K, int VW>
+__device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x,
+                                                     const float* __restrict__ gy,
+                                                     const float* __restrict__ wt,
+                                                     float* __restrict__ gx, const PPShape& sh,
+                                                     const BasisTab& tab, const DenseCoord& dc,
+                                                     float* wl) {
+  constexpr int vw = VW;
+  constexpr int kBuf = K * 32 * kWStride;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b0 = (blockIdx.x * 4 + wave) * 32;
   const int i0 = blockIdx.y * 32;
   const int b = min(b0 + r, sh.B - 1);
-  const int nrows = min(32, sh.I - i0) * K;  // weight rows (i,k) this tile owns, contiguous in w_t
+  const int nrows = min(32, sh.I - i0) * K;  // (input, k) weight rows of this tile: contiguous in w_t
+  const bool wave_on = b0 < sh.B;
 
   f32x16 acc[K];
 #pragma unroll
@@ -155,80 +246,158 @@ __global__ __launch_bounds__(256) void pp_bwd_input_dense_kernel(const float* __
 
   const float* grow = gy + (size_t)b * sh.O;
   const float* wbase = wt + (size_t)i0 * K * sh.O;
-  for (int oc0 = 0; oc0 < sh.O; oc0 += 32) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * K * 32; idx += 256) {
-      const int rowid = idx >> 5, oo = idx & 31;  // rowid = ri*K + k
-      const int ri = rowid / K, k = rowid - ri * K;
-      float v = 0.0f;
-      if (rowid < nrows && oc0 + oo < sh.O) v = wbase[(size_t)rowid * sh.O + oc0 + oo];
-      wl[(k * 32 + ri) * 33 + oo] = v;
+  const int nchunk = (sh.O + 31) >> 5;
+
+  // staging slot m of this thread: tile row (t + 256 m) / 8, floats 4*((t + 256 m) % 8) .. +3
+  float stage[K][4];
+  auto stage_load = [&](int c) {
+    const int oc0 = c * 32;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+      const int slot = threadIdx.x + 256 * m;
+      const int rowid = slot >> 3, part = (slot & 7) * 4;
+      const int o = oc0 + part;
+      if (rowid < nrows && o < sh.O) {
+        load_pieces<4, VW>(wbase + (size_t)rowid * sh.O + o, sh.O - vw - o, stage[m]);
+#pragma unroll
+        for (int e = 1; e < 4; ++e)
+          if (o + e >= sh.O) stage[m][e] = 0.0f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stage[m][e] = 0.0f;
+      }
     }
-    __syncthreads();
-    if (b0 < sh.B) {  // wave-uniform
-#pragma unroll 4
-      for (int t = 0; t < 16; ++t) {
-        const int oo = 2 * t + h;
-        const float a = (oc0 + oo < sh.O) ? grow[oc0 + oo] : 0.0f;
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+      const int slot = threadIdx.x + 256 * m;
+      const int rowid = slot >> 3, part = (slot & 7) * 4;
+      const int ri = rowid / K, k = rowid - ri * K;
+      *reinterpret_cast<float4*>(&wl[buf * kBuf + (k * 32 + ri) * kWStride + part]) =
+          make_float4(stage[m][0], stage[m][1], stage[m][2], stage[m][3]);
+    }
+  };
+  float g[4][4];  // gy of the current chunk: group t -> outs oc0 + 8t + 4h + 0..3
+  auto gy_load = [&](int c, float (&dst)[4][4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = c * 32 + 8 * t + 4 * h;
+      if (o < sh.O) {
+        load_pieces<4, VW>(grow + o, sh.O - vw - o, dst[t]);
+#pragma unroll
+        for (int e = 1; e < 4; ++e)
+          if (o + e >= sh.O) dst[t][e] = 0.0f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[t][e] = 0.0f;
+      }
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  gy_load(0, g);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    float gn[4][4];
+    const bool more = c + 1 < nchunk;  // block-uniform
+    if (more) {
+      stage_load(c + 1);
+      gy_load(c + 1, gn);
+    }
+    if (wave_on) {
+      const float* wb = wl + buf * kBuf + r * kWStride + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float4 wv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          wv[k] = *reinterpret_cast<const float4*>(wb + k * 32 * kWStride + 8 * t);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const float bv = wl[(k * 32 + r) * 33 + oo];
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][0], wv[k].x, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][1], wv[k].y, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][2], wv[k].z, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][3], wv[k].w, acc[k], 0, 0, 0);
         }
       }
     }
+    if (more) {
+      stage_store(buf ^ 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[t][e] = gn[t][e];
+    }
+    __syncthreads();
   }
-  if (b0 >= sh.B) return;
+  if (!wave_on) return;
   // epilogue: lane owns input column i0+r for 16 rows
   const int i = i0 + r;
   if (i < sh.I) {
+    const float chain = (sh.length * dc.inv_w) * sh.out_scale;  // dxi/dx = L/(2/S)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = b0 + (q & 3) + 8 * (q >> 2) + 4 * h;
       if (row < sh.B) {
         const float xv = x[(size_t)row * sh.I + i];
         int s;
-        float xi, dxi_dx;
-        dense_seg_xi(xv, sh, dc, s, xi, dxi_dx);
+        float xi;
+        dense_seg_xi(xv, sh, dc, s, xi);
         float l[N], dl[N], dphi[K];
         pp_lagrange_d<N>(xi, tab, l, dl);
         expand_basis<N, K>(dl, s * sh.stride, dphi);
-        float g = 0.0f;
+        float gsum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) g = fmaf(dphi[k], acc[k][q], g);
-        gx[(size_t)row * sh.I + i] = g * (dxi_dx * sh.out_scale);
+        for (int k = 0; k < K; ++k) gsum = fmaf(dphi[k], acc[k][q], gsum);
+        gx[(size_t)row * sh.I + i] = gsum * chain;
       }
     }
   }
 }
 
+template <int N, int K>
+__global__ __launch_bounds__(256) void pp_bwd_input_dense_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ gy,
+                                                                 const float* __restrict__ wt,
+                                                                 float* __restrict__ gx,
+                                                                 PPShape sh, BasisTab tab,
+                                                                 DenseCoord dc, int vw) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // 2 x [K][32][kWStride]
+  if (vw == 4) bwd_input_dense_body<N, K, 4>(x, gy, wt, gx, sh, tab, dc, wl);
+  else if (vw == 2) bwd_input_dense_body<N, K, 2>(x, gy, wt, gx, sh, tab, dc, wl);
+  else bwd_input_dense_body<N, K, 1>(x, gy, wt, gx, sh, tab, dc, wl);
+}
+
 // ---------------------------------------------------------------------------
-// backward-weight: block = one (32 inputs x 32 outputs) tile x one row chunk;
-// its 4 waves split the chunk's rows, accumulate K tiles each, and are summed
-// through LDS.  k-slots = two rows.  Partials (one per row chunk) go to the
+// backward-weight: block = NW waves = NW adjacent 32-wide `out` tiles of one
+// 32-input tile, over one chunk of rows.  Rows are consumed two per MFMA step
+// (k-slots = rows b, b+1).  Phi is shared through LDS: in every group of NW
+// steps, wave w evaluates the basis of step w once and publishes its K columns;
+// after one barrier all NW waves run the group's NW*K MFMAs, each against its
+// own gy column tile.  So the VALU work per MFMA falls by NW and the basis of a
+// (row, input) pair is evaluated once per block.  Per-chunk partials go to the
 // workspace and are summed in a fixed order by pp_dense_reduce_kernel.
 // ---------------------------------------------------------------------------
-template <int N, int K>
-__global__ __launch_bounds__(256) void pp_bwd_weight_dense_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ gy,
-                                                                  float* __restrict__ out,
-                                                                  PPShape sh, BasisTab tab,
-                                                                  DenseCoord dc, int rows_per_chunk,
-                                                                  float scale) {
-  __shared__ float red[4 * 16 * 64];
+template <int N, int K, int NW>
+__global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ out, PPShape sh,
+    BasisTab tab, DenseCoord dc, int rows_per_chunk, float scale) {
+  __shared__ float phil[2][NW][K][64];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.x * 32;
-  const int o0 = blockIdx.y * 32;
+  const int o0 = (blockIdx.y * NW + wave) * 32;
   const int chunk = blockIdx.z;
   const int cbeg = chunk * rows_per_chunk;
   const int cend = min(sh.B, cbeg + rows_per_chunk);
-  // wave w takes rows cbeg + 2*(w + 4*t) + h
   const int i = i0 + r;
-  const bool ivalid = i < sh.I;
-  const int ic = ivalid ? i : sh.I - 1;
+  const int ic = min(i, sh.I - 1);
   const int oc = min(o0 + r, sh.O - 1);
+  const bool wave_on = o0 < sh.O;  // this wave's out tile exists
 
   f32x16 acc[K];
 #pragma unroll
@@ -236,92 +405,126 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_dense_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
 
-  for (int bb = cbeg + 2 * wave; bb < cend; bb += 8) {
-    const int b = bb + h;
-    const bool bvalid = b < cend;
-    const int bc = bvalid ? b : cend - 1;
-    const float xv = x[(size_t)bc * sh.I + ic];
-    const float gv = bvalid ? gy[(size_t)bc * sh.O + oc] : 0.0f;
+  const int nstep = (cend - cbeg + 1) >> 1;
+  const int ngroup = (nstep + NW - 1) / NW;
+
+  auto produce = [&](int grp, int buf) {  // wave w publishes Phi of step grp*NW + w
+    const int bb = cbeg + 2 * (grp * NW + wave) + h;
+    const bool valid = bb < cend;
+    const float xv = x[(size_t)min(bb, cend - 1) * sh.I + ic];
+    float phi[K];
     int s;
-    float xi, dd;
-    dense_seg_xi(xv, sh, dc, s, xi, dd);
-    float l[N], phi[K];
-    pp_lagrange<N>(xi, tab, l);
-    expand_basis<N, K>(l, s * sh.stride, phi);
+    phi_of_x<N, K>(xv, valid, sh, tab, dc, phi, s);
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], gv, acc[k], 0, 0, 0);
-  }
-  // cross-wave sum through LDS, one k at a time; wave 0 writes
-  float* dst = out + (size_t)chunk * sh.I * K * sh.O;
+    for (int k = 0; k < K; ++k) phil[buf][wave][k][lane] = phi[k];
+  };
+
+  produce(0, 0);
+  __syncthreads();
+  for (int grp = 0; grp < ngroup; ++grp) {
+    const int buf = grp & 1;
+    // gy of this group's steps for this wave's column tile (issued before the LDS/VALU work)
+    float gv[NW];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    __syncthreads();
+    for (int w = 0; w < NW; ++w) {
+      const int bb = cbeg + 2 * (grp * NW + w) + h;
+      gv[w] = (bb < cend && wave_on) ? gy[(size_t)bb * sh.O + oc] : 0.0f;
+    }
+    if (grp + 1 < ngroup) produce(grp + 1, buf ^ 1);
+    if (wave_on) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[k][q];
-    __syncthreads();
-    if (wave == 0) {
+      for (int w = 0; w < NW; ++w) {
+        float phi[K];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float v = (red[(0 * 16 + q) * 64 + lane] + red[(1 * 16 + q) * 64 + lane]) +
-                        (red[(2 * 16 + q) * 64 + lane] + red[(3 * 16 + q) * 64 + lane]);
-        const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;  // input index
-        const int col = o0 + r;
-        if (row < sh.I && col < sh.O) dst[((size_t)row * K + k) * sh.O + col] = v * scale;
+        for (int k = 0; k < K; ++k) phi[k] = phil[buf][w][k][lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], gv[w], acc[k], 0, 0, 0);
       }
     }
+    __syncthreads();
+  }
+  if (!wave_on) return;
+  float* dst = out + (size_t)chunk * sh.I * K * sh.O;
+  const int col = o0 + r;
+  if (col < sh.O) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;  // input index
+        if (row < sh.I) dst[((size_t)row * K + k) * sh.O + col] = acc[k][q] * scale;
+      }
   }
 }
 
-__global__ __launch_bounds__(256) void pp_dense_reduce_kernel(const float* __restrict__ part,
-                                                              float* __restrict__ gwt, long total,
+template <typename T>
+__global__ __launch_bounds__(256) void pp_dense_reduce_kernel(const T* __restrict__ part,
+                                                              T* __restrict__ gwt, long total,
                                                               int nchunk, float scale) {
   long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long step = (long)gridDim.x * 256;
   for (; idx < total; idx += step) {
-    float s = 0.0f;
-    for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * total + idx];
+    T s = part[idx];
+    for (int c = 1; c < nchunk; ++c) s += part[(size_t)c * total + idx];
     gwt[idx] = s * scale;
   }
 }
 
 DenseCoord make_coord(const PPShape& sh) {
   DenseCoord dc;
-  int e;
-  const bool len_pow2 = std::frexp(sh.length, &e) == 0.5f;
-  const bool s_pow2 = (sh.S & (sh.S - 1)) == 0;
-  dc.exact = (len_pow2 && s_pow2) ? 1 : 0;
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
   return dc;
 }
 
+bool is_exact(const PPShape& sh) {
+  int e;
+  const bool len_pow2 = std::frexp(sh.length, &e) == 0.5f;
+  const bool s_pow2 = (sh.S & (sh.S - 1)) == 0;
+  return len_pow2 && s_pow2;
+}
+
+int vec_width(int O) { return O % 4 == 0 ? 4 : (O % 2 == 0 ? 2 : 1); }
+
+int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
 struct WeightPlan {
-  int nchunk, rows_per_chunk;
+  int nw, ncol, nchunk, rows_per_chunk;
 };
 
 WeightPlan weight_plan(const PPShape& sh) {
-  const int tiles = ((sh.I + 31) / 32) * ((sh.O + 31) / 32);
-  // aim for >= 2 blocks per CU, at least 64 rows per wave
-  int nchunk = (512 + tiles - 1) / tiles;
-  const int max_chunks = std::max(1, sh.B / 256);
+  WeightPlan p;
+  const int otiles = (sh.O + 31) / 32;
+  p.nw = otiles > 4 ? 8 : 4;
+  p.ncol = (otiles + p.nw - 1) / p.nw;
+  const int tiles = ((sh.I + 31) / 32) * p.ncol;
+  const int target = env_int("PP_DENSE_BWDW_BLOCKS", 256);
+  int nchunk = (target + tiles - 1) / tiles;
+  const int max_chunks = std::max(1, sh.B / (16 * p.nw));  // >= 8 groups of NW steps per block
   nchunk = std::max(1, std::min(nchunk, max_chunks));
   int rpc = (sh.B + nchunk - 1) / nchunk;
-  rpc = (rpc + 7) & ~7;
-  nchunk = (sh.B + rpc - 1) / rpc;
-  return {nchunk, rpc};
+  rpc = (rpc + 2 * p.nw - 1) / (2 * p.nw) * (2 * p.nw);
+  p.rows_per_chunk = rpc;
+  p.nchunk = (sh.B + rpc - 1) / rpc;
+  return p;
 }
 
-// (N, K) pairs with K <= 8 that a continuous or discontinuous layer can produce
+// (N, K) pairs with K <= 8 that an exact (S = 1, 2, 4 or 8) layer can produce
 #define PP_DENSE_COMBOS(X) \
-  X(1, 2) X(1, 3) X(1, 4) X(1, 5) X(1, 6) X(1, 7) X(1, 8) \
-  X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) \
-  X(3, 5) X(3, 6) X(3, 7) X(4, 7) X(4, 8)
+  X(1, 1) X(1, 2) X(1, 4) X(1, 8) \
+  X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 8) \
+  X(3, 3) X(3, 5) X(3, 6) X(4, 4) X(4, 7) X(4, 8) \
+  X(5, 5) X(6, 6) X(7, 7) X(8, 8)
 
 }  // namespace
 
 bool pp_dense_supported(const PPShape& sh) {
+  if (!is_exact(sh)) return false;
 #define X(N_, K_) if (sh.n == N_ && sh.K == K_) return true;
   PP_DENSE_COMBOS(X)
 #undef X
@@ -337,13 +540,18 @@ size_t pp_dense_bwd_weight_workspace_bytes(const PPShape& sh) {
 hipError_t pp_launch_fwd_dense(const float* x, const float* wt, float* y, int32_t* seg,
                                const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const DenseCoord dc = make_coord(sh);
-  constexpr int NT = 2;
-  dim3 grid((sh.B + 127) / 128, (sh.O + 32 * NT - 1) / (32 * NT));
-#define X(N_, K_)                                                                              \
-  if (sh.n == N_ && sh.K == K_) {                                                              \
-    hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, NT>), grid, dim3(256), 0, st, x, wt, y, seg, \
-                       sh, tab, dc);                                                           \
-    return hipGetLastError();                                                                  \
+  const int vw = vec_width(sh.O);
+  const int nt = env_int("PP_DENSE_FWD_NT", sh.O > 64 ? 4 : 2);
+  dim3 grid((sh.B + 127) / 128, (sh.O + 32 * nt - 1) / (32 * nt));
+#define X(N_, K_)                                                                                 \
+  if (sh.n == N_ && sh.K == K_) {                                                                 \
+    if (nt == 4)                                                                                  \
+      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 4>), grid, dim3(256), 0, st, x, wt, y, seg, \
+                         sh, tab, dc, vw);                                                        \
+    else                                                                                          \
+      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 2>), grid, dim3(256), 0, st, x, wt, y, seg, \
+                         sh, tab, dc, std::min(vw, 2));                                           \
+    return hipGetLastError();                                                                     \
   }
   PP_DENSE_COMBOS(X)
 #undef X
@@ -354,12 +562,22 @@ hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const floa
                                      const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   if (sh.n == 1) return hipMemsetAsync(gx, 0, (size_t)sh.B * sh.I * sizeof(float), st);
   const DenseCoord dc = make_coord(sh);
+  const int vw = vec_width(sh.O);
   dim3 grid((sh.B + 127) / 128, (sh.I + 31) / 32);
-#define X(N_, K_)                                                                               \
-  if (sh.n == N_ && sh.K == K_) {                                                               \
-    hipLaunchKernelGGL((pp_bwd_input_dense_kernel<N_, K_>), grid, dim3(256), 0, st, x, gy, wt, gx, \
-                       sh, tab, dc);                                                            \
-    return hipGetLastError();                                                                   \
+#define X(N_, K_)                                                                              \
+  if (sh.n == N_ && sh.K == K_) {                                                              \
+    const size_t lds = 2 * (size_t)K_ * 32 * kWStride * sizeof(float);                         \
+    if (lds > 48 * 1024) {                                                                     \
+      static bool once = false;                                                                \
+      if (!once) {                                                                             \
+        (void)hipFuncSetAttribute((const void*)pp_bwd_input_dense_kernel<N_, K_>,                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        once = true;                                                                           \
+      }                                                                                        \
+    }                                                                                          \
+    hipLaunchKernelGGL((pp_bwd_input_dense_kernel<N_, K_>), grid, dim3(256), lds, st, x, gy, wt, \
+                       gx, sh, tab, dc, vw);                                                   \
+    return hipGetLastError();                                                                  \
   }
   PP_DENSE_COMBOS(X)
 #undef X
@@ -370,15 +588,19 @@ hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gw
                                       const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const DenseCoord dc = make_coord(sh);
   const WeightPlan p = weight_plan(sh);
-  dim3 grid((sh.I + 31) / 32, (sh.O + 31) / 32, p.nchunk);
+  dim3 grid((sh.I + 31) / 32, p.ncol, p.nchunk);
   float* out = p.nchunk > 1 ? static_cast<float*>(ws) : gwt;
   const float scale = p.nchunk > 1 ? 1.0f : sh.out_scale;
   bool launched = false;
-#define X(N_, K_)                                                                                \
-  if (!launched && sh.n == N_ && sh.K == K_) {                                                   \
-    hipLaunchKernelGGL((pp_bwd_weight_dense_kernel<N_, K_>), grid, dim3(256), 0, st, x, gy, out, \
-                       sh, tab, dc, p.rows_per_chunk, scale);                                    \
-    launched = true;                                                                             \
+#define X(N_, K_)                                                                              \
+  if (!launched && sh.n == N_ && sh.K == K_) {                                                 \
+    if (p.nw == 8)                                                                             \
+      hipLaunchKernelGGL((pp_bwd_weight_dense_kernel<N_, K_, 8>), grid, dim3(512), 0, st, x, gy, \
+                         out, sh, tab, dc, p.rows_per_chunk, scale);                           \
+    else                                                                                       \
+      hipLaunchKernelGGL((pp_bwd_weight_dense_kernel<N_, K_, 4>), grid, dim3(256), 0, st, x, gy, \
+                         out, sh, tab, dc, p.rows_per_chunk, scale);                           \
+    launched = true;                                                                           \
   }
   PP_DENSE_COMBOS(X)
 #undef X
@@ -386,8 +608,15 @@ hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gw
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || p.nchunk <= 1) return e;
   const long total = (long)sh.I * sh.K * sh.O;
-  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(pp_dense_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                     (const float*)ws, gwt, total, p.nchunk, sh.out_scale);
+  if (total % 4 == 0) {
+    const long t4 = total / 4;
+    const int blocks = (int)std::min<long>((t4 + 255) / 256, 2048);
+    hipLaunchKernelGGL((pp_dense_reduce_kernel<float4>), dim3(blocks), dim3(256), 0, st,
+                       (const float4*)ws, (float4*)gwt, t4, p.nchunk, sh.out_scale);
+  } else {
+    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL((pp_dense_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st,
+                       (const float*)ws, gwt, total, p.nchunk, sh.out_scale);
+  }
   return hipGetLastError();
 }

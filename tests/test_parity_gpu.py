@@ -91,9 +91,11 @@ def test_gather_and_both_scatter_variants(case):
     check(hip_all(x, w, gy, n, S, disc, "gather", "gather", "sort"), ref, "gather/sort")
 
 
-DENSE_CASES = [c for c in CASES if 2 <= (c[1] * c[2] if c[0] else (c[1] - 1) * c[2] + 1) <= 8] + [
+DENSE_CASES = [c for c in CASES if (c[1] * c[2] if c[0] else (c[1] - 1) * c[2] + 1) <= 8
+               and c[2] & (c[2] - 1) == 0] + [
     (True, 2, 4, 40, 70, 100, "edges"),     # K=8, non power-of-two free
-    (False, 2, 3, 33, 31, 77, "normal"),    # S=3: inexact-width branch
+    (False, 2, 4, 33, 31, 77, "normal"),    # K=5 from n=2, S=4; odd widths -> scalar loads
+    (False, 3, 1, 34, 66, 50, "normal"),    # single segment: a plain polynomial layer
     (True, 1, 8, 64, 64, 300, "normal"),
     (False, 4, 2, 100, 96, 130, "normal"),  # K=7
     (False, 3, 2, 250, 250, 4096, "normal"),  # several row chunks in the weight gradient
@@ -113,6 +115,16 @@ def test_dense_mfma_methods(case):
         check(got3, ref3, "dense/length4")
 
 
+def test_dense_rejects_inexact_layers():
+    """S or length not a power of two -> the dense kernels refuse (gather path serves them)."""
+    from language_interpolation_amd._lib import PPHipError
+    x, w, gy = make_inputs(16, 33, 31, 2, 3, False, "normal", seed=6)
+    with pytest.raises(PPHipError):
+        hip_all(x, w, gy, 2, 3, False, "dense", "gather", "atomic")
+    ref = oracle_all(x, w, gy, 2, 3, False)
+    check(hip_all(x, w, gy, 2, 3, False), ref, "auto S=3")
+
+
 def test_golden_vectors():
     z = np.load(GOLDEN, allow_pickle=False)
     for name in sorted({k.split("/")[0] for k in z.files}):
@@ -122,7 +134,7 @@ def test_golden_vectors():
         for bw in ("atomic", "sort", "auto"):
             check(hip_all(x, w, gy, n, S, bool(disc), bwd_w=bw), ref, f"{name}/{bw}")
         K = n * S if disc else (n - 1) * S + 1
-        if K <= 8:
+        if K <= 8 and S & (S - 1) == 0:
             check(hip_all(x, w, gy, n, S, bool(disc), "dense", "dense", "dense"), ref,
                   f"{name}/dense")
 
