@@ -74,27 +74,43 @@ __device__ __forceinline__ void phi_of_x(float xv, bool valid, const PPShape& sh
   expand_basis<N, K>(l, s * sh.stride, phi);
 }
 
-// W floats starting at p, fetched as VW-wide pieces (VW in {4,2,1}); p is aligned
-// to VW floats.  Piece m is taken from p + min(m, lim) so that a tile hanging over
-// the end of a row still reads valid memory (masked later).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+// Raw buffer descriptor over [p, p+bytes): loads take an SGPR base + one 32-bit
+// VGPR offset + an SGPR offset, so the MFMA loops carry no 64-bit address
+// arithmetic, and reads past `bytes` return 0 instead of faulting (row / column
+// tails need no clamping).  p and bytes are kernel arguments (wave-uniform).
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// W floats at byte offset voff (VGPR) + soff (SGPR), fetched as VW-wide pieces.
 template <int W, int VW>
-__device__ __forceinline__ void load_pieces(const float* p, int lim, float (&v)[W]) {
+__device__ __forceinline__ void bload(rsrc_t r, int voff, int soff, float (&v)[W]) {
   if constexpr (W >= 4 && VW == 4) {
 #pragma unroll
     for (int m = 0; m < W; m += 4) {
-      const float4 t = *reinterpret_cast<const float4*>(p + min(m, lim));
-      v[m] = t.x; v[m + 1] = t.y; v[m + 2] = t.z; v[m + 3] = t.w;
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 4 * m, soff, 0);
+      v[m] = __uint_as_float(t.x); v[m + 1] = __uint_as_float(t.y);
+      v[m + 2] = __uint_as_float(t.z); v[m + 3] = __uint_as_float(t.w);
     }
   } else if constexpr (W >= 2 && VW >= 2) {
 #pragma unroll
     for (int m = 0; m < W; m += 2) {
-      const float2 t = *reinterpret_cast<const float2*>(p + min(m, lim));
-      v[m] = t.x; v[m + 1] = t.y;
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 4 * m, soff, 0);
+      v[m] = __uint_as_float(t.x); v[m + 1] = __uint_as_float(t.y);
     }
   } else {
 #pragma unroll
-    for (int m = 0; m < W; ++m) v[m] = p[min(m, lim)];
+    for (int m = 0; m < W; ++m)
+      v[m] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff + 4 * m, soff, 0));
   }
+}
+
+__device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 // ---------------------------------------------------------------------------
@@ -106,10 +122,8 @@ __device__ __forceinline__ void load_pieces(const float* p, int lim, float (&v)[
 template <int N, int K, int NT, int VW>
 __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
                                                const float* __restrict__ wt,
-                                               float* __restrict__ y,
-                                               int32_t* __restrict__ seg_out, const PPShape& sh,
+                                               float* __restrict__ y, const PPShape& sh,
                                                const BasisTab& tab, const DenseCoord& dc) {
-  constexpr int vw = VW;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -117,9 +131,12 @@ __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
   if (b0 >= sh.B) return;
   const int o0 = blockIdx.y * (32 * NT);
   const int b = min(b0 + r, sh.B - 1);
-  const bool write_seg = seg_out != nullptr && blockIdx.y == 0 && (b0 + r) < sh.B;
-  const int ocl = min(o0 + NT * r, sh.O - vw);  // first column this lane loads (clamped)
-  const int lim = sh.O - vw - ocl;              // largest in-row piece offset
+  const rsrc_t rw = make_rsrc(wt, (unsigned)sh.I * sh.K * sh.O * 4u);
+  const rsrc_t rx = make_rsrc(x, (unsigned)sh.B * sh.I * 4u);
+  const int rowb = sh.O * 4;                              // bytes per weight row
+  const int vw_off = (h * K * sh.O + o0 + NT * r) * 4;    // lane-constant part of the W address
+  const int vx_off = (b * sh.I + h) * 4;
+  const int pair_w = 2 * K * rowb;                        // W bytes per input pair
 
   f32x16 acc[NT];
 #pragma unroll
@@ -127,39 +144,34 @@ __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
 
-  const float* xrow = x + (size_t)b * sh.I;
   const int npair = (sh.I + 1) >> 1;
-  const int ilast = sh.I - 1;
-
   float wc[K][NT], wn[K][NT], phic[K], phin[K];
-  int sc;
-  {
-    const int i = min(h, ilast);
-    phi_of_x<N, K>(xrow[i], h <= ilast, sh, tab, dc, phic, sc);
-    if (write_seg && h <= ilast) seg_out[(size_t)b * sh.I + h] = sc;
-    const float* wrow = wt + (size_t)i * K * sh.O + ocl;
+  int s_unused;
+  phi_of_x<N, K>(bload1(rx, vx_off, 0), h < sh.I, sh, tab, dc, phic, s_unused);
 #pragma unroll
-    for (int k = 0; k < K; ++k) load_pieces<NT, VW>(wrow + (size_t)k * sh.O, lim, wc[k]);
-  }
-  float x1 = xrow[min(2 + h, ilast)];  // pair 1
+  for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, k * rowb, wc[k]);
+  float x1 = bload1(rx, vx_off, 8);  // pair 1
+  int sw = pair_w;                   // SGPR byte offset of pair ip+1's weights
   for (int ip = 0; ip < npair; ++ip) {
-    // prefetch: weights of pair ip+1, x of pair ip+2
-    const int i1 = 2 * (ip + 1) + h;
-    const int i1c = min(i1, ilast);
-    const float* wrow = wt + (size_t)i1c * K * sh.O + ocl;
+    // prefetch: weights of pair ip+1 (reads past the last input return 0), x of pair ip+2
 #pragma unroll
-    for (int k = 0; k < K; ++k) load_pieces<NT, VW>(wrow + (size_t)k * sh.O, lim, wn[k]);
-    const float x2 = xrow[min(2 * (ip + 2) + h, ilast)];
+    for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, sw + k * rowb, wn[k]);
+    const float x2 = bload1(rx, vx_off, 8 * (ip + 2));
     // basis of pair ip+1 (independent of the MFMAs below)
-    int sn;
-    phi_of_x<N, K>(x1, i1 <= ilast, sh, tab, dc, phin, sn);
-    if (write_seg && i1 <= ilast) seg_out[(size_t)b * sh.I + i1] = sn;
+    phi_of_x<N, K>(x1, 2 * (ip + 1) + h < sh.I, sh, tab, dc, phin, s_unused);
     // MFMAs of pair ip
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phic[k], wc[k][nt], acc[nt], 0, 0, 0);
+#ifdef PP_SCHED_INTERLEAVE
+#pragma unroll
+    for (int q = 0; q < K * NT; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, PP_SCHED_INTERLEAVE, 0);
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       phic[k] = phin[k];
@@ -167,6 +179,7 @@ __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
       for (int nt = 0; nt < NT; ++nt) wc[k][nt] = wn[k][nt];
     }
     x1 = x2;
+    sw += pair_w;
   }
   // epilogue: lane holds NT consecutive columns for 16 rows
   const int oc = o0 + NT * r;
@@ -198,14 +211,12 @@ __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
 template <int N, int K, int NT>
 __global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wt,
-                                                           float* __restrict__ y,
-                                                           int32_t* __restrict__ seg_out,
-                                                           PPShape sh, BasisTab tab,
-                                                           DenseCoord dc, int vw) {
+                                                           float* __restrict__ y, PPShape sh,
+                                                           BasisTab tab, DenseCoord dc, int vw) {
   // vw is wave-uniform: one straight-line body per load width
-  if (NT >= 4 && vw == 4) fwd_dense_body<N, K, NT, (NT >= 4 ? 4 : 2)>(x, wt, y, seg_out, sh, tab, dc);
-  else if (vw >= 2) fwd_dense_body<N, K, NT, 2>(x, wt, y, seg_out, sh, tab, dc);
-  else fwd_dense_body<N, K, NT, 1>(x, wt, y, seg_out, sh, tab, dc);
+  if (NT >= 4 && vw == 4) fwd_dense_body<N, K, NT, (NT >= 4 ? 4 : 2)>(x, wt, y, sh, tab, dc);
+  else if (vw >= 2) fwd_dense_body<N, K, NT, 2>(x, wt, y, sh, tab, dc);
+  else fwd_dense_body<N, K, NT, 1>(x, wt, y, sh, tab, dc);
 }
 
 // ---------------------------------------------------------------------------
@@ -215,8 +226,8 @@ __global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restri
 // into registers while the current chunk's MFMAs run, then written to the other
 // LDS buffer (one barrier per chunk).  Rows are padded to 36 floats so that the
 // ds_read_b128 of 4 consecutive outs per lane is bank-conflict-free.  Lane (r,h)
-// takes outs 8t+4h..+3 of each group of 8: one 16-byte gy load and K
-// ds_read_b128 feed 4K MFMAs.
+// takes outs 8t+4h..+3 of each group of 8: one 16-byte gy load (prefetched one
+// group ahead) and K ds_read_b128 feed 4K MFMAs.
 // ---------------------------------------------------------------------------
 constexpr int kWStride = 36;
 
@@ -227,7 +238,6 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
                                                      float* __restrict__ gx, const PPShape& sh,
                                                      const BasisTab& tab, const DenseCoord& dc,
                                                      float* wl) {
-  constexpr int vw = VW;
   constexpr int kBuf = K * 32 * kWStride;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -235,8 +245,14 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
   const int b0 = (blockIdx.x * 4 + wave) * 32;
   const int i0 = blockIdx.y * 32;
   const int b = min(b0 + r, sh.B - 1);
-  const int nrows = min(32, sh.I - i0) * K;  // (input, k) weight rows of this tile: contiguous in w_t
   const bool wave_on = b0 < sh.B;
+  const int rowb = sh.O * 4;
+  // this tile's (input, k) weight rows are contiguous in w_t: a sub-buffer whose end
+  // is the end of the tile's (or the matrix') rows, so rows past the tile read as 0
+  const int nrows = min(32, sh.I - i0) * K;
+  const rsrc_t rw = make_rsrc(wt + (size_t)i0 * K * sh.O, (unsigned)nrows * rowb);
+  const rsrc_t rg = make_rsrc(gy, (unsigned)sh.B * rowb);
+  const int vg_off = b * rowb + 16 * h;  // gy: row b, outs 4h.. of each group of 8
 
   f32x16 acc[K];
 #pragma unroll
@@ -244,93 +260,80 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
 
-  const float* grow = gy + (size_t)b * sh.O;
-  const float* wbase = wt + (size_t)i0 * K * sh.O;
   const int nchunk = (sh.O + 31) >> 5;
+  const bool ragged = (sh.O & 31) != 0;
 
   // staging slot m of this thread: tile row (t + 256 m) / 8, floats 4*((t + 256 m) % 8) .. +3
+  int srow[K], slds[K];
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    const int slot = threadIdx.x + 256 * m;
+    const int rowid = slot >> 3, part = (slot & 7) * 4;
+    const int ri = rowid / K, k = rowid - ri * K;
+    srow[m] = rowid * rowb + part * 4;
+    slds[m] = (k * 32 + ri) * kWStride + part;
+  }
   float stage[K][4];
   auto stage_load = [&](int c) {
-    const int oc0 = c * 32;
 #pragma unroll
-    for (int m = 0; m < K; ++m) {
-      const int slot = threadIdx.x + 256 * m;
-      const int rowid = slot >> 3, part = (slot & 7) * 4;
-      const int o = oc0 + part;
-      if (rowid < nrows && o < sh.O) {
-        load_pieces<4, VW>(wbase + (size_t)rowid * sh.O + o, sh.O - vw - o, stage[m]);
+    for (int m = 0; m < K; ++m) bload<4, VW>(rw, srow[m], c * 128, stage[m]);
+    if (ragged && c == nchunk - 1) {  // block-uniform: zero the columns past O
 #pragma unroll
-        for (int e = 1; e < 4; ++e)
+      for (int m = 0; m < K; ++m) {
+        const int o = c * 32 + ((threadIdx.x + 256 * m) & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
           if (o + e >= sh.O) stage[m][e] = 0.0f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) stage[m][e] = 0.0f;
       }
     }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int m = 0; m < K; ++m) {
-      const int slot = threadIdx.x + 256 * m;
-      const int rowid = slot >> 3, part = (slot & 7) * 4;
-      const int ri = rowid / K, k = rowid - ri * K;
-      *reinterpret_cast<float4*>(&wl[buf * kBuf + (k * 32 + ri) * kWStride + part]) =
+    for (int m = 0; m < K; ++m)
+      *reinterpret_cast<float4*>(&wl[buf * kBuf + slds[m]]) =
           make_float4(stage[m][0], stage[m][1], stage[m][2], stage[m][3]);
-    }
   };
-  float g[4][4];  // gy of the current chunk: group t -> outs oc0 + 8t + 4h + 0..3
-  auto gy_load = [&](int c, float (&dst)[4][4]) {
+  // gy of group q = 4*chunk + t: outs 8q + 4h + 0..3 of row b (zero past O)
+  auto gy_load = [&](int q, float (&dst)[4]) {
+    bload<4, VW>(rg, vg_off, q * 32, dst);
+    const int o = 8 * q + 4 * h;
+    if (ragged && o + 4 > sh.O) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int o = c * 32 + 8 * t + 4 * h;
-      if (o < sh.O) {
-        load_pieces<4, VW>(grow + o, sh.O - vw - o, dst[t]);
-#pragma unroll
-        for (int e = 1; e < 4; ++e)
-          if (o + e >= sh.O) dst[t][e] = 0.0f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[t][e] = 0.0f;
-      }
+      for (int e = 0; e < 4; ++e)
+        if (o + e >= sh.O) dst[e] = 0.0f;
     }
   };
 
   stage_load(0);
   stage_store(0);
+  float g[4], gn[4];
   gy_load(0, g);
   __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
-    float gn[4][4];
     const bool more = c + 1 < nchunk;  // block-uniform
-    if (more) {
-      stage_load(c + 1);
-      gy_load(c + 1, gn);
-    }
+    if (more) stage_load(c + 1);
     if (wave_on) {
       const float* wb = wl + buf * kBuf + r * kWStride + 4 * h;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        gy_load(4 * c + t + 1, gn);  // past the last group: zero-masked / out of range
         float4 wv[K];
 #pragma unroll
         for (int k = 0; k < K; ++k)
           wv[k] = *reinterpret_cast<const float4*>(wb + k * 32 * kWStride + 8 * t);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][0], wv[k].x, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][1], wv[k].y, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][2], wv[k].z, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[t][3], wv[k].w, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[0], wv[k].x, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[1], wv[k].y, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2], wv[k].z, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[3], wv[k].w, acc[k], 0, 0, 0);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = gn[e];
       }
     }
-    if (more) {
-      stage_store(buf ^ 1);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[t][e] = gn[t][e];
-    }
+    if (more) stage_store(buf ^ 1);
     __syncthreads();
   }
   if (!wave_on) return;
@@ -378,8 +381,9 @@ __global__ __launch_bounds__(256) void pp_bwd_input_dense_kernel(const float* __
 // steps, wave w evaluates the basis of step w once and publishes its K columns;
 // after one barrier all NW waves run the group's NW*K MFMAs, each against its
 // own gy column tile.  So the VALU work per MFMA falls by NW and the basis of a
-// (row, input) pair is evaluated once per block.  Per-chunk partials go to the
-// workspace and are summed in a fixed order by pp_dense_reduce_kernel.
+// (row, input) pair is evaluated once per block.  x and gy are prefetched one
+// group ahead.  Per-chunk partials go to the workspace and are summed in a fixed
+// order by pp_dense_reduce_kernel.
 // ---------------------------------------------------------------------------
 template <int N, int K, int NW>
 __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
@@ -394,10 +398,15 @@ __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
   const int chunk = blockIdx.z;
   const int cbeg = chunk * rows_per_chunk;
   const int cend = min(sh.B, cbeg + rows_per_chunk);
-  const int i = i0 + r;
-  const int ic = min(i, sh.I - 1);
+  const int ic = min(i0 + r, sh.I - 1);
   const int oc = min(o0 + r, sh.O - 1);
   const bool wave_on = o0 < sh.O;  // this wave's out tile exists
+  // sub-buffers ending at the chunk's last row: rows past the chunk read as 0
+  const rsrc_t rx = make_rsrc(x + (size_t)cbeg * sh.I, (unsigned)(cend - cbeg) * sh.I * 4u);
+  const rsrc_t rg = make_rsrc(gy + (size_t)cbeg * sh.O, (unsigned)(cend - cbeg) * sh.O * 4u);
+  const int vx_off = ((2 * wave + h) * sh.I + ic) * 4;  // step `wave` of a group, row parity h
+  const int vg_off = (h * sh.O + oc) * 4;
+  const int grp_x = 2 * NW * sh.I * 4, grp_g = 2 * NW * sh.O * 4, step_g = 2 * sh.O * 4;
 
   f32x16 acc[K];
 #pragma unroll
@@ -408,10 +417,8 @@ __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
   const int nstep = (cend - cbeg + 1) >> 1;
   const int ngroup = (nstep + NW - 1) / NW;
 
-  auto produce = [&](int grp, int buf) {  // wave w publishes Phi of step grp*NW + w
-    const int bb = cbeg + 2 * (grp * NW + wave) + h;
-    const bool valid = bb < cend;
-    const float xv = x[(size_t)min(bb, cend - 1) * sh.I + ic];
+  auto publish = [&](float xv, int grp, int buf) {  // wave w publishes Phi of step grp*NW + w
+    const bool valid = cbeg + 2 * (grp * NW + wave) + h < cend;
     float phi[K];
     int s;
     phi_of_x<N, K>(xv, valid, sh, tab, dc, phi, s);
@@ -419,18 +426,19 @@ __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
     for (int k = 0; k < K; ++k) phil[buf][wave][k][lane] = phi[k];
   };
 
-  produce(0, 0);
+  float gv[NW], gvn[NW];
+  publish(bload1(rx, vx_off, 0), 0, 0);
+  float xn = bload1(rx, vx_off, grp_x);  // group 1
+#pragma unroll
+  for (int w = 0; w < NW; ++w) gv[w] = bload1(rg, vg_off, w * step_g);
   __syncthreads();
   for (int grp = 0; grp < ngroup; ++grp) {
     const int buf = grp & 1;
-    // gy of this group's steps for this wave's column tile (issued before the LDS/VALU work)
-    float gv[NW];
+    // prefetch gy of group grp+1 and x of group grp+2 (past the chunk: 0)
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int bb = cbeg + 2 * (grp * NW + w) + h;
-      gv[w] = (bb < cend && wave_on) ? gy[(size_t)bb * sh.O + oc] : 0.0f;
-    }
-    if (grp + 1 < ngroup) produce(grp + 1, buf ^ 1);
+    for (int w = 0; w < NW; ++w) gvn[w] = bload1(rg, vg_off, (grp + 1) * grp_g + w * step_g);
+    const float xn2 = bload1(rx, vx_off, (grp + 2) * grp_x);
+    if (grp + 1 < ngroup) publish(xn, grp + 1, buf ^ 1);
     if (wave_on) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
@@ -442,6 +450,9 @@ __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
           acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], gv[w], acc[k], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gv[w] = gvn[w];
+    xn = xn2;
     __syncthreads();
   }
   if (!wave_on) return;
@@ -525,6 +536,11 @@ WeightPlan weight_plan(const PPShape& sh) {
 
 bool pp_dense_supported(const PPShape& sh) {
   if (!is_exact(sh)) return false;
+  // buffer loads address with 32-bit byte offsets
+  const long lim = 1L << 31;
+  if ((long)sh.B * sh.I * 4 >= lim || (long)sh.B * sh.O * 4 >= lim ||
+      (long)sh.I * sh.K * sh.O * 4 >= lim)
+    return false;
 #define X(N_, K_) if (sh.n == N_ && sh.K == K_) return true;
   PP_DENSE_COMBOS(X)
 #undef X
@@ -546,12 +562,15 @@ hipError_t pp_launch_fwd_dense(const float* x, const float* wt, float* y, int32_
 #define X(N_, K_)                                                                                 \
   if (sh.n == N_ && sh.K == K_) {                                                                 \
     if (nt == 4)                                                                                  \
-      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 4>), grid, dim3(256), 0, st, x, wt, y, seg, \
-                         sh, tab, dc, vw);                                                        \
+      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 4>), grid, dim3(256), 0, st, x, wt, y, sh, \
+                         tab, dc, vw);                                                        \
     else                                                                                          \
-      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 2>), grid, dim3(256), 0, st, x, wt, y, seg, \
-                         sh, tab, dc, std::min(vw, 2));                                           \
-    return hipGetLastError();                                                                     \
+      hipLaunchKernelGGL((pp_fwd_dense_kernel<N_, K_, 2>), grid, dim3(256), 0, st, x, wt, y, sh, \
+                         tab, dc, std::min(vw, 2));                                           \
+    hipError_t e = hipGetLastError();                                                             \
+    /* ids: same fp32 expression (the exact reciprocal forms are bit-identical) */                \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                        \
+    return e;                                                                                     \
   }
   PP_DENSE_COMBOS(X)
 #undef X
