@@ -145,42 +145,44 @@ __device__ __forceinline__ void fwd_dense_body(const float* __restrict__ x,
     for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
 
   const int npair = (sh.I + 1) >> 1;
-  float wc[K][NT], wn[K][NT], phic[K], phin[K];
+  // three register sets (A/B/C) used round-robin, so no copies and no early waits:
+  // while the MFMAs of pair p read one set, the other two receive the weights of
+  // pairs p+1 (already in flight) and p+2 (issued now); the basis of pair p+1 is
+  // evaluated under the MFMAs of pair p.  x runs 3 pairs ahead.
+  float wA[K][NT], wB[K][NT], wC[K][NT], phiA[K], phiB[K], phiC[K];
   int s_unused;
-  phi_of_x<N, K>(bload1(rx, vx_off, 0), h < sh.I, sh, tab, dc, phic, s_unused);
+  phi_of_x<N, K>(bload1(rx, vx_off, 0), h < sh.I, sh, tab, dc, phiA, s_unused);
 #pragma unroll
-  for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, k * rowb, wc[k]);
-  float x1 = bload1(rx, vx_off, 8);  // pair 1
-  int sw = pair_w;                   // SGPR byte offset of pair ip+1's weights
-  for (int ip = 0; ip < npair; ++ip) {
-    // prefetch: weights of pair ip+1 (reads past the last input return 0), x of pair ip+2
+  for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, k * rowb, wA[k]);
 #pragma unroll
-    for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, sw + k * rowb, wn[k]);
-    const float x2 = bload1(rx, vx_off, 8 * (ip + 2));
-    // basis of pair ip+1 (independent of the MFMAs below)
-    phi_of_x<N, K>(x1, 2 * (ip + 1) + h < sh.I, sh, tab, dc, phin, s_unused);
-    // MFMAs of pair ip
+  for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, pair_w + k * rowb, wB[k]);
+  float x0 = bload1(rx, vx_off, 8), x1 = bload1(rx, vx_off, 16), x2 = bload1(rx, vx_off, 24);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing in flight
+
+  // one pair ip: issue the weights of pair ip+2 into w2, evaluate the basis of pair
+  // ip+1 (its x is in xr) into phi1, refill xr with pair ip+4, run the MFMAs of pair
+  // ip from (w0, phi0).  Reads past the last input return 0.
+  auto step = [&](int ip, const float (&w0)[K][NT], const float (&phi0)[K], float (&phi1)[K],
+                  float (&w2)[K][NT], float& xr) {
+    const int sw = (ip + 2) * pair_w;
+#pragma unroll
+    for (int k = 0; k < K; ++k) bload<NT, VW>(rw, vw_off, sw + k * rowb, w2[k]);
+    phi_of_x<N, K>(xr, 2 * (ip + 1) + h < sh.I, sh, tab, dc, phi1, s_unused);
+    xr = bload1(rx, vx_off, 8 * (ip + 4));
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phic[k], wc[k][nt], acc[nt], 0, 0, 0);
-#ifdef PP_SCHED_INTERLEAVE
-#pragma unroll
-    for (int q = 0; q < K * NT; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, PP_SCHED_INTERLEAVE, 0);
-    }
-#endif
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      phic[k] = phin[k];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wc[k][nt] = wn[k][nt];
-    }
-    x1 = x2;
-    sw += pair_w;
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi0[k], w0[k][nt], acc[nt], 0, 0, 0);
+  };
+  int ip = 0;
+  for (; ip + 2 < npair; ip += 3) {
+    step(ip, wA, phiA, phiB, wC, x0);
+    step(ip + 1, wB, phiB, phiC, wA, x1);
+    step(ip + 2, wC, phiC, phiA, wB, x2);
   }
+  if (ip < npair) step(ip, wA, phiA, phiB, wC, x0);
+  if (ip + 1 < npair) step(ip + 1, wB, phiB, phiC, wA, x1);
   // epilogue: lane holds NT consecutive columns for 16 rows
   const int oc = o0 + NT * r;
 #pragma unroll
@@ -296,8 +298,8 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
   // gy of group q = 4*chunk + t: outs 8q + 4h + 0..3 of row b (zero past O)
   auto gy_load = [&](int q, float (&dst)[4]) {
     bload<4, VW>(rg, vg_off, q * 32, dst);
-    const int o = 8 * q + 4 * h;
-    if (ragged && o + 4 > sh.O) {
+    if (ragged && q >= 4 * (nchunk - 1)) {  // wave-uniform: only the last chunk has a tail
+      const int o = 8 * q + 4 * h;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (o + e >= sh.O) dst[e] = 0.0f;
@@ -306,32 +308,33 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
 
   stage_load(0);
   stage_store(0);
-  float g[4], gn[4];
-  gy_load(0, g);
+  float gA[4], gB[4];
+  gy_load(0, gA);
   __syncthreads();
+  auto group = [&](const float* wb, int t, int q, const float (&g)[4], float (&gn)[4]) {
+    gy_load(q + 1, gn);  // past the last group: zero-masked / out of range
+    float4 wv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      wv[k] = *reinterpret_cast<const float4*>(wb + k * 32 * kWStride + 8 * t);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[0], wv[k].x, acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[1], wv[k].y, acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2], wv[k].z, acc[k], 0, 0, 0);
+      acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[3], wv[k].w, acc[k], 0, 0, 0);
+    }
+  };
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     const bool more = c + 1 < nchunk;  // block-uniform
     if (more) stage_load(c + 1);
-    if (wave_on) {
+    {  // waves past the last row tile run on clamped rows (no divergent control flow here)
       const float* wb = wl + buf * kBuf + r * kWStride + 4 * h;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        gy_load(4 * c + t + 1, gn);  // past the last group: zero-masked / out of range
-        float4 wv[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          wv[k] = *reinterpret_cast<const float4*>(wb + k * 32 * kWStride + 8 * t);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[0], wv[k].x, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[1], wv[k].y, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2], wv[k].z, acc[k], 0, 0, 0);
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[3], wv[k].w, acc[k], 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = gn[e];
-      }
+      group(wb, 0, 4 * c + 0, gA, gB);
+      group(wb, 1, 4 * c + 1, gB, gA);
+      group(wb, 2, 4 * c + 2, gA, gB);
+      group(wb, 3, 4 * c + 3, gB, gA);
     }
     if (more) stage_store(buf ^ 1);
     __syncthreads();
@@ -426,35 +429,40 @@ __global__ __launch_bounds__(NW * 64) void pp_bwd_weight_dense_kernel(
     for (int k = 0; k < K; ++k) phil[buf][wave][k][lane] = phi[k];
   };
 
-  float gv[NW], gvn[NW];
+  float gvA[NW], gvB[NW];
   publish(bload1(rx, vx_off, 0), 0, 0);
   float xn = bload1(rx, vx_off, grp_x);  // group 1
 #pragma unroll
-  for (int w = 0; w < NW; ++w) gv[w] = bload1(rg, vg_off, w * step_g);
+  for (int w = 0; w < NW; ++w) gvA[w] = bload1(rg, vg_off, w * step_g);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
-  for (int grp = 0; grp < ngroup; ++grp) {
+  // one group: prefetch gy of group grp+1 (into gvn) and x of group grp+2, publish the
+  // basis of group grp+1, run this group's NW*K MFMAs from (LDS Phi, gv).
+  auto group = [&](int grp, const float (&gv)[NW], float (&gvn)[NW]) {
     const int buf = grp & 1;
-    // prefetch gy of group grp+1 and x of group grp+2 (past the chunk: 0)
 #pragma unroll
     for (int w = 0; w < NW; ++w) gvn[w] = bload1(rg, vg_off, (grp + 1) * grp_g + w * step_g);
     const float xn2 = bload1(rx, vx_off, (grp + 2) * grp_x);
     if (grp + 1 < ngroup) publish(xn, grp + 1, buf ^ 1);
-    if (wave_on) {
+    // (waves whose out tile does not exist run on a clamped column and skip the store)
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        float phi[K];
+    for (int w = 0; w < NW; ++w) {
+      float phi[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) phi[k] = phil[buf][w][k][lane];
+      for (int k = 0; k < K; ++k) phi[k] = phil[buf][w][k][lane];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], gv[w], acc[k], 0, 0, 0);
-      }
+      for (int k = 0; k < K; ++k)
+        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], gv[w], acc[k], 0, 0, 0);
     }
-#pragma unroll
-    for (int w = 0; w < NW; ++w) gv[w] = gvn[w];
     xn = xn2;
     __syncthreads();
+  };
+  int grp = 0;
+  for (; grp + 1 < ngroup; grp += 2) {
+    group(grp, gvA, gvB);
+    group(grp + 1, gvB, gvA);
   }
+  if (grp < ngroup) group(grp, gvA, gvB);
   if (!wave_on) return;
   float* dst = out + (size_t)chunk * sh.I * K * sh.O;
   const int col = o0 + r;

@@ -1,59 +1,68 @@
-// Calibration: how many ns does a v_mfma_f32_32x32x2_f32 take on this chip,
-// back-to-back from registers, at 1, 2 and 4 waves per SIMD?  (developer tool)
+// Calibration (developer tool): cost of v_mfma_f32_32x32x2_f32 back-to-back from
+// registers, alone and with NV independent VALU instructions per MFMA in the same
+// wave (does vector work hide under the f32 MFMA?).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NACC>
+template <int NACC, int NV>
 __global__ __launch_bounds__(256) void probe(float* out, int iters, float a0, float b0) {
   f32x16 acc[NACC];
   for (int n = 0; n < NACC; ++n)
     for (int q = 0; q < 16; ++q) acc[n][q] = 0.f;
   float a = a0 + threadIdx.x, b = b0;
+  float v[8];
+  for (int j = 0; j < 8; ++j) v[j] = a0 * j;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int n = 0; n < NACC; ++n)
+      for (int n = 0; n < NACC; ++n) {
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j & 7] = __builtin_fmaf(v[j & 7], b, a);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+      }
   }
   float s = 0;
   for (int n = 0; n < NACC; ++n)
     for (int q = 0; q < 16; ++q) s += acc[n][q];
+  for (int j = 0; j < 8; ++j) s += v[j];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NACC>
+template <int NACC, int NV>
 void run(int blocks, int iters) {
   float* out;
-  hipMalloc(&out, blocks * 256 * 4);
+  (void)hipMalloc(&out, blocks * 256 * 4);
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<NACC><<<blocks, 256>>>(out, iters, 1.f, 2.f);
-  hipDeviceSynchronize();
-  hipEventRecord(e0);
-  probe<NACC><<<blocks, 256>>>(out, iters, 1.f, 2.f);
-  hipEventRecord(e1);
-  hipDeviceSynchronize();
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  probe<NACC, NV><<<blocks, 256>>>(out, iters, 1.f, 2.f);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  probe<NACC, NV><<<blocks, 256>>>(out, iters, 1.f, 2.f);
+  (void)hipEventRecord(e1);
+  (void)hipDeviceSynchronize();
   float ms;
-  hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
   double mfma_per_wave = (double)iters * 4 * NACC;
   double waves_per_simd = blocks / 256.0;
   double ns = ms * 1e6 / (mfma_per_wave * waves_per_simd);
-  double tf = (double)blocks * 4 * mfma_per_wave * 32 * 32 * 2 * 2 / (ms * 1e-3) * 1e-12;
-  printf("NACC=%d blocks=%d (%.0f waves/SIMD): %.3f ms, %.2f ns per MFMA per SIMD, %.1f TFLOP/s\n",
-         NACC, blocks, waves_per_simd, ms, ns, tf);
-  hipFree(out);
+  printf("NACC=%d NV=%d blocks=%d (%.0f waves/SIMD): %.2f ns per MFMA per SIMD\n", NACC, NV, blocks,
+         waves_per_simd, ns);
+  (void)hipFree(out);
 }
 
 int main() {
-  for (int rep = 0; rep < 2; ++rep) {
-    run<1>(256, 20000);
-    run<2>(256, 10000);
-    run<4>(256, 5000);
-    run<4>(512, 5000);
-    run<4>(1024, 5000);
-    run<1>(1024, 20000);
-  }
+  run<4, 0>(256, 5000);
+  run<4, 0>(256, 5000);
+  run<4, 1>(256, 5000);
+  run<4, 2>(256, 5000);
+  run<4, 4>(256, 5000);
+  run<4, 8>(256, 5000);
+  run<4, 12>(256, 5000);
+  run<4, 4>(512, 5000);
+  run<4, 8>(512, 5000);
   return 0;
 }
