@@ -122,6 +122,22 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
 int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream);
 int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* stream);
 
+/* Non-affine LayerNorm over the last dim (what LazyLayerNormLastDim computes:
+ * /root/reference/language_interpolation/networks.py:72-91, eps 1e-5, weight/bias
+ * frozen at 1/0).  y[B,D] = (x - mean)/sqrt(var + eps); rstd[B] is saved for the
+ * backward, which works from the OUTPUT y: gx = rstd*(gy - mean(gy) - y*mean(gy*y)).
+ * D <= 1024. */
+int pp_layer_norm_fwd_f32(const float* x, float* y, float* rstd, int B, int D, float eps,
+                          void* stream);
+int pp_layer_norm_bwd_f32(const float* y, const float* gy, const float* rstd, float* gx, int B,
+                          int D, void* stream);
+
+/* MaxAbsNormalizationLast of high-order-layers-torch (selected at networks.py:58-59):
+ * y = x / (max|x| over the last dim + eps); backward needs x and gy. D <= 1024. */
+int pp_max_abs_norm_fwd_f32(const float* x, float* y, int B, int D, float eps, void* stream);
+int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, int D, float eps,
+                            void* stream);
+
 /* Which method PP_METHOD_AUTO resolves to for a shape (for logs and tests).
  * pass: 0 forward, 1 backward-input, 2 backward-weight. */
 int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous);

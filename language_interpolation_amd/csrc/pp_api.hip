@@ -196,4 +196,45 @@ int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* s
   return hip_rc(pp_launch_transpose(w_t, w, I * K, O, (hipStream_t)stream));
 }
 
+static int norm_args_ok(int B, int D) {
+  if (B < 1 || D < 1 || D > 1024) return PP_ERR_SHAPE;
+  if ((long)B * D >= (1L << 31)) return PP_ERR_RANGE;
+  return PP_OK;
+}
+
+int pp_layer_norm_fwd_f32(const float* x, float* y, float* rstd, int B, int D, float eps,
+                          void* stream) {
+  if (!x || !y || !rstd) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(y)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_layer_norm_fwd(x, y, rstd, B, D, eps, (hipStream_t)stream));
+}
+
+int pp_layer_norm_bwd_f32(const float* y, const float* gy, const float* rstd, float* gx, int B,
+                          int D, void* stream) {
+  if (!y || !gy || !rstd || !gx) return PP_ERR_NULL;
+  if (!aligned16(y) || !aligned16(gy) || !aligned16(gx)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_layer_norm_bwd(y, gy, rstd, gx, B, D, (hipStream_t)stream));
+}
+
+int pp_max_abs_norm_fwd_f32(const float* x, float* y, int B, int D, float eps, void* stream) {
+  if (!x || !y) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(y)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_max_abs_fwd(x, y, B, D, eps, (hipStream_t)stream));
+}
+
+int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, int D, float eps,
+                            void* stream) {
+  if (!x || !gy || !gx) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(gy) || !aligned16(gx)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_max_abs_bwd(x, gy, gx, B, D, eps, (hipStream_t)stream));
+}
+
 }  // extern "C"

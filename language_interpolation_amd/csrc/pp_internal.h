@@ -43,3 +43,12 @@ hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const floa
                                      const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gwt, void* ws,
                                       const PPShape& sh, const BasisTab& tab, hipStream_t st);
+
+// ---- row-wise normalisations (pp_norm.hip) ----
+hipError_t pp_launch_layer_norm_fwd(const float* x, float* y, float* rstd, int B, int D, float eps,
+                                    hipStream_t st);
+hipError_t pp_launch_layer_norm_bwd(const float* y, const float* gy, const float* rstd, float* gx,
+                                    int B, int D, hipStream_t st);
+hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float eps, hipStream_t st);
+hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
+                                 hipStream_t st);

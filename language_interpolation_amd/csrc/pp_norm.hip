@@ -1,0 +1,223 @@
+// Row-wise normalisations that sit between the polynomial layers
+// (/root/reference/language_interpolation/networks.py:48-91):
+//   LazyLayerNormLastDim  -> non-affine LayerNorm over the last dim, eps 1e-5
+//   MaxAbsNormalizationLast -> x / (max|x| + eps), eps 1e-6                   
+// HBM-bound streaming kernels: one wavefront per row, the row held in registers
+// (D <= 1024), 16-byte accesses where D allows, DPP wave reductions.  The
+// LayerNorm backward works from the OUTPUT y (which the next layer keeps alive
+// anyway) and the saved 1/std, so the forward writes only y and rstd[B].
+#include "pp_device.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Row cache: CH chunks of 64 lanes x V floats.
+template <int V, int CH>
+struct RowRegs {
+  float v[CH][V];
+  __device__ __forceinline__ void load(const float* row, int D, int lane, float fill) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int d = (c * 64 + lane) * V;
+      if (d < D) {
+        PPVec<V> t;
+        t.load(row + d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[c][e] = t.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[c][e] = fill;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* row, int D, int lane) const {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int d = (c * 64 + lane) * V;
+      if (d < D) {
+        PPVec<V> t;
+#pragma unroll
+        for (int e = 0; e < V; ++e) t.v[e] = v[c][e];
+        t.store(row + d);
+      }
+    }
+  }
+};
+
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_layer_norm_fwd_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ y,
+                                                                float* __restrict__ rstd, int B,
+                                                                int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> r;
+  r.load(x + (size_t)row * D, D, lane, 0.0f);
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) s += r.v[c][e];
+  const float mean = pp_wave_sum(s) / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const bool in = (c * 64 + lane) * V + e < D;
+      const float d = in ? r.v[c][e] - mean : 0.0f;
+      r.v[c][e] = d;
+      q = fmaf(d, d, q);
+    }
+  const float var = pp_wave_sum(q) / (float)D;
+  const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[c][e] *= rs;
+  r.store(y + (size_t)row * D, D, lane);
+  if (lane == 0) rstd[row] = rs;
+}
+
+// gx = rstd * (gy - mean(gy) - y * mean(gy*y))
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_layer_norm_bwd_kernel(const float* __restrict__ y,
+                                                                const float* __restrict__ gy,
+                                                                const float* __restrict__ rstd,
+                                                                float* __restrict__ gx, int B,
+                                                                int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> ry, rg;
+  ry.load(y + (size_t)row * D, D, lane, 0.0f);
+  rg.load(gy + (size_t)row * D, D, lane, 0.0f);
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      s1 += rg.v[c][e];
+      s2 = fmaf(rg.v[c][e], ry.v[c][e], s2);
+    }
+  const float m1 = pp_wave_sum(s1) / (float)D;
+  const float m2 = pp_wave_sum(s2) / (float)D;
+  const float rs = rstd[row];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) rg.v[c][e] = rs * (rg.v[c][e] - m1 - ry.v[c][e] * m2);
+  rg.store(gx + (size_t)row * D, D, lane);
+}
+
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_max_abs_fwd_kernel(const float* __restrict__ x,
+                                                             float* __restrict__ y, int B, int D,
+                                                             float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> r;
+  r.load(x + (size_t)row * D, D, lane, 0.0f);
+  float m = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) m = fmaxf(m, fabsf(r.v[c][e]));
+  const float den = wave_max(m) + eps;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[c][e] = r.v[c][e] / den;
+  r.store(y + (size_t)row * D, D, lane);
+}
+
+// y = x/d, d = |x_a| + eps, a = first argmax|x|:
+// gx_j = gy_j/d - [j==a] * sign(x_a) * sum_k(gy_k x_k) / d^2
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_max_abs_bwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gy,
+                                                             float* __restrict__ gx, int B, int D,
+                                                             float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> rx, rg;
+  rx.load(x + (size_t)row * D, D, lane, 0.0f);
+  rg.load(gy + (size_t)row * D, D, lane, 0.0f);
+  float m = 0.0f, s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      m = fmaxf(m, fabsf(rx.v[c][e]));
+      s = fmaf(rg.v[c][e], rx.v[c][e], s);
+    }
+  const float mx = wave_max(m);
+  const float dot = pp_wave_sum(s);
+  // first index attaining the max
+  int idx = 0x7fffffff;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int d = (c * 64 + lane) * V + e;
+      if (d < D && fabsf(rx.v[c][e]) == mx) idx = min(idx, d);
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) idx = min(idx, __shfl_xor(idx, off, 64));
+  const float den = mx + eps;
+  const float corr = dot / (den * den);
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int d = (c * 64 + lane) * V + e;
+      float g = rg.v[c][e] / den;
+      if (d == idx) g -= (rx.v[c][e] < 0.0f ? -corr : corr);
+      rg.v[c][e] = g;
+    }
+  rg.store(gx + (size_t)row * D, D, lane);
+}
+
+}  // namespace
+
+// dispatch on (vector width, chunks): D <= 64*V*CH
+#define PP_NORM_DISPATCH(KERNEL, ...)                                                      \
+  do {                                                                                     \
+    const int V = (D % 4 == 0) ? 4 : (D % 2 == 0 ? 2 : 1);                                 \
+    const int need = (D + 64 * V - 1) / (64 * V);                                          \
+    dim3 grid((B + 3) / 4), block(256);                                                    \
+    if (V == 4 && need <= 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 4 && need <= 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 4 && need <= 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 8) hipLaunchKernelGGL((KERNEL<2, 8>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 1 && need <= 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 1 && need <= 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, block, 0, st, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                      \
+    return hipGetLastError();                                                              \
+  } while (0)
+
+hipError_t pp_launch_layer_norm_fwd(const float* x, float* y, float* rstd, int B, int D, float eps,
+                                    hipStream_t st) {
+  PP_NORM_DISPATCH(pp_layer_norm_fwd_kernel, x, y, rstd, B, D, eps);
+}
+hipError_t pp_launch_layer_norm_bwd(const float* y, const float* gy, const float* rstd, float* gx,
+                                    int B, int D, hipStream_t st) {
+  PP_NORM_DISPATCH(pp_layer_norm_bwd_kernel, y, gy, rstd, gx, B, D);
+}
+hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float eps, hipStream_t st) {
+  PP_NORM_DISPATCH(pp_max_abs_fwd_kernel, x, y, B, D, eps);
+}
+hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
+                                 hipStream_t st) {
+  PP_NORM_DISPATCH(pp_max_abs_bwd_kernel, x, gy, gx, B, D, eps);
+}

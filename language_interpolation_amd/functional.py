@@ -199,3 +199,103 @@ class PiecewisePolyFunction(torch.autograd.Function):
 
 def piecewise_poly(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> torch.Tensor:
     return PiecewisePolyFunction.apply(x, w, spec)
+
+
+# ---------------------------------------------------------------------------
+# row-wise normalisations between the layers (HIP kernels in csrc/pp_norm.hip)
+# ---------------------------------------------------------------------------
+NORM_MAX_D = 1024
+
+
+def _rows(t: torch.Tensor):
+    D = t.shape[-1]
+    return t.reshape(-1, D).contiguous(), D
+
+
+class LayerNormLastFunction(torch.autograd.Function):
+    """Non-affine LayerNorm over the last dim; saves (y, rstd), not x."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, eps: float):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        x2, D = _rows(x)
+        B = x2.shape[0]
+        y = torch.empty_like(x2)
+        rstd = torch.empty(max(B, 1), device=x.device, dtype=torch.float32)
+        if B > 0:
+            with torch.cuda.device(x.device):
+                rc = lib.pp_layer_norm_fwd_f32(_ptr(x2), _ptr(y), _ptr(rstd), B, D, eps,
+                                               _stream(x.device))
+            _lib.check(rc, "pp_layer_norm_fwd_f32")
+        ctx.save_for_backward(y, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        lib = _lib.load()
+        y, rstd = ctx.saved_tensors
+        B, D = y.shape
+        gy2 = gy.reshape(-1, D).contiguous()
+        if gy2.dtype != torch.float32:
+            gy2 = gy2.float()
+        gx = torch.empty_like(y)
+        if B > 0:
+            with torch.cuda.device(y.device):
+                rc = lib.pp_layer_norm_bwd_f32(_ptr(y), _ptr(gy2), _ptr(rstd), _ptr(gx), B, D,
+                                               _stream(y.device))
+            _lib.check(rc, "pp_layer_norm_bwd_f32")
+        return gx.view(ctx.shape), None
+
+
+class MaxAbsLastFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, eps: float):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        x2, D = _rows(x)
+        B = x2.shape[0]
+        y = torch.empty_like(x2)
+        if B > 0:
+            with torch.cuda.device(x.device):
+                rc = lib.pp_max_abs_norm_fwd_f32(_ptr(x2), _ptr(y), B, D, eps, _stream(x.device))
+            _lib.check(rc, "pp_max_abs_norm_fwd_f32")
+        ctx.save_for_backward(x2)
+        ctx.eps = eps
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        lib = _lib.load()
+        (x2,) = ctx.saved_tensors
+        B, D = x2.shape
+        gy2 = gy.reshape(-1, D).contiguous()
+        if gy2.dtype != torch.float32:
+            gy2 = gy2.float()
+        gx = torch.empty_like(x2)
+        if B > 0:
+            with torch.cuda.device(x2.device):
+                rc = lib.pp_max_abs_norm_bwd_f32(_ptr(x2), _ptr(gy2), _ptr(gx), B, D, ctx.eps,
+                                                 _stream(x2.device))
+            _lib.check(rc, "pp_max_abs_norm_bwd_f32")
+        return gx.view(ctx.shape), None
+
+
+def _hip_norm_ok(x: torch.Tensor) -> bool:
+    """GPU fp32 tensors with a last dim the row-in-registers kernels hold go to HIP (and fail
+    loudly there if the library is missing); CPU tensors and wider rows use plain torch ops."""
+    return x.is_cuda and x.dtype == torch.float32 and 1 <= x.shape[-1] <= NORM_MAX_D
+
+
+def layer_norm_last(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    if _hip_norm_ok(x):
+        return LayerNormLastFunction.apply(x, eps)
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), None, None, eps)
+
+
+def max_abs_norm_last(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    if _hip_norm_ok(x):
+        return MaxAbsLastFunction.apply(x, eps)
+    return x / (x.abs().max(dim=-1, keepdim=True)[0] + eps)

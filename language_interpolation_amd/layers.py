@@ -158,7 +158,7 @@ class MaxAbsNormalizationLast(nn.Module):
         self._eps = eps
 
     def forward(self, x: Tensor) -> Tensor:
-        return x / (x.abs().max(dim=-1, keepdim=True)[0] + self._eps)
+        return PF.max_abs_norm_last(x, self._eps)
 
 
 class MaxCenterNormalizationLast(nn.Module):
@@ -188,4 +188,4 @@ class LazyLayerNormLastDim(nn.Module):
         self.bias = bias
 
     def forward(self, input: Tensor) -> Tensor:
-        return torch.nn.functional.layer_norm(input, (input.shape[-1],), None, None, 1e-5)
+        return PF.layer_norm_last(input, 1e-5)

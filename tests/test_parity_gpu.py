@@ -252,3 +252,30 @@ def test_module_autograd_path_and_empty_batch():
     # reshape_apply on [b, l, d]
     out = L.reshape_apply(torch.rand(7, 5, 16, device="cuda") * 2 - 1, net)
     assert out.shape == (7, 5, 12)
+
+
+@pytest.mark.parametrize("D", [2, 7, 64, 128, 200, 250, 251, 256, 1000, 1024])
+def test_norm_kernels_match_oracle(D):
+    """LayerNorm (networks.py:72-91) and MaxAbs normalisation: forward and backward vs the
+    fp64 torch restatement in oracle/pp_oracle.py."""
+    from oracle import pp_oracle as po
+    PF = _pf()
+    gen = torch.Generator().manual_seed(D)
+    B = 37
+    x = torch.randn(B, D, generator=gen) * 2 + 0.3
+    gy = torch.randn(B, D, generator=gen)
+    for hip_fn, ora_fn, tol in ((PF.layer_norm_last, po.layer_norm_last_dim, 2e-5),
+                                (PF.max_abs_norm_last, po.max_abs_normalization_last, 1e-5)):
+        if D == 1 and hip_fn is PF.layer_norm_last:
+            continue  # variance of one element: y == 0, gradient ill-defined
+        xg = x.cuda().requires_grad_(True)
+        y = hip_fn(xg)
+        y.backward(gy.cuda())
+        xo = x.double().requires_grad_(True)
+        yo = ora_fn(xo)
+        yo.backward(gy.double())
+        assert rel_err(y.detach(), yo.detach()) <= tol, hip_fn.__name__
+        assert rel_err(xg.grad, xo.grad) <= 5 * tol, hip_fn.__name__
+    # leading dims are flattened like the reference's modules allow
+    x3 = torch.randn(3, 5, D, generator=gen).cuda()
+    assert PF.layer_norm_last(x3).shape == x3.shape
