@@ -37,25 +37,41 @@ struct DenseCoord {
 __device__ __forceinline__ void dense_seg_xi(float x, const PPShape& sh, const DenseCoord& dc,
                                              int& s, float& xi) {
   const float t = ((x + sh.half) * dc.inv_len) * sh.Sf;
-  s = 0;
-  if (t > -9.2e18f && t < 9.2e18f) {
-    const float tc = fminf(fmaxf(t, -1.0f), sh.Sf);
-    s = (int)tc;
-    s = s < 0 ? 0 : (s > sh.S - 1 ? sh.S - 1 : s);
-  }
+  // branch-free form of pp_segment(): clamp, truncate, clamp; non-finite / huge t -> 0
+  const float tc = __builtin_amdgcn_fmed3f(t, -1.0f, sh.Sf);
+  int si = (int)tc;
+  si = min(max(si, 0), sh.S - 1);
+  s = (__builtin_fabsf(t) < 9.2e18f) ? si : 0;
   const float x_min = (float)s * dc.w2 - 1.0f;  // == (s/S)*2-1 exactly
   xi = sh.length * ((x - x_min) * dc.inv_w) - sh.half;
 }
 
-// Phi[k] for k = 0..K-1 from the n active basis values (zeros elsewhere).
+// (N, K) fixes the layer type on this path (S must be a power of two):
+// K % N == 0 with K/N a power of two -> discontinuous (stride N), else continuous.
 template <int N, int K>
-__device__ __forceinline__ void expand_basis(const float (&l)[N], int soff, float (&phi)[K]) {
+struct DenseGeom {
+  static constexpr bool disc = (K % N == 0) && (((K / N) & (K / N - 1)) == 0);
+  static constexpr int stride = disc ? N : N - 1;
+  static constexpr int S = disc ? K / N : (N > 1 ? (K - 1) / (N - 1) : K);
+};
+
+// Phi[k] for k = 0..K-1 from the n active basis values (zeros elsewhere): for each k
+// only the segments s' with 0 <= k - s'*stride < N can contribute, so the select
+// runs over those compile-time candidates (S compares + <= 2 v_cndmask per k).
+template <int N, int K>
+__device__ __forceinline__ void expand_basis(const float (&l)[N], int s, float (&phi)[K]) {
+  constexpr int S = DenseGeom<N, K>::S, stride = DenseGeom<N, K>::stride;
+  bool is[S];
+#pragma unroll
+  for (int q = 0; q < S; ++q) is[q] = (s == q);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int j = k - soff;
     float v = 0.0f;
 #pragma unroll
-    for (int jj = 0; jj < N; ++jj) v = (j == jj) ? l[jj] : v;
+    for (int q = 0; q < S; ++q) {
+      const int j = k - q * stride;
+      if (j >= 0 && j < N) v = is[q] ? l[j] : v;
+    }
     phi[k] = v;
   }
 }
@@ -71,7 +87,7 @@ __device__ __forceinline__ void phi_of_x(float xv, bool valid, const PPShape& sh
 #pragma unroll
     for (int j = 0; j < N; ++j) l[j] = 0.0f;
   }
-  expand_basis<N, K>(l, s * sh.stride, phi);
+  expand_basis<N, K>(l, s, phi);
 }
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -222,6 +238,126 @@ __global__ __launch_bounds__(256) void pp_fwd_dense_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------
+// forward, shared-basis variant: block = 8 waves = RT row tiles x CW column waves
+// (CW*RT = 8), each wave a 32-row x 64-out tile (NT = 2).  The basis of a (row
+// tile, input pair) is evaluated ONCE per block: in every group of CW pairs, column
+// wave cw evaluates pair g*CW+cw of its row tile and publishes the K columns in
+// LDS; after one barrier all CW waves of the row tile run the group's CW*K*2 MFMAs
+// from LDS-read Phi and their own weight columns.  VALU work per MFMA falls by CW
+// (VALU does not hide under the f32 MFMA on gfx950), and with 8 waves per CU the
+// waits of one wave sit under the MFMAs of its SIMD partner.
+// ---------------------------------------------------------------------------
+template <int N, int K, int CW, int RT, int VW>
+__device__ __forceinline__ void fwd_dense_shared_body(const float* __restrict__ x,
+                                                      const float* __restrict__ wt,
+                                                      float* __restrict__ y, const PPShape& sh,
+                                                      const BasisTab& tab, const DenseCoord& dc,
+                                                      float* phil) {
+  constexpr int NT = 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int rt = wave / CW, cw = wave - rt * CW;
+  const int r = lane & 31, h = lane >> 5;
+  const int b0 = (blockIdx.x * RT + rt) * 32;
+  const int o0 = (blockIdx.y * CW + cw) * (32 * NT);
+  const int b = min(b0 + r, sh.B - 1);
+  const rsrc_t rw = make_rsrc(wt, (unsigned)sh.I * sh.K * sh.O * 4u);
+  const rsrc_t rx = make_rsrc(x, (unsigned)sh.B * sh.I * 4u);
+  const int rowb = sh.O * 4;
+  const int vw_off = (h * K * sh.O + min(o0 + NT * r, sh.O - VW)) * 4;
+  const int vx_off = (b * sh.I + 2 * cw + h) * 4;  // this wave produces pair g*CW + cw
+  const int pair_w = 2 * K * rowb;
+  const int npair = (sh.I + 1) >> 1;
+  const int ngroup = (npair + CW - 1) / CW;
+  // LDS: phil[buf][rt][p][k][lane]
+  float* my_phi = phil + (size_t)rt * CW * K * 64;
+  constexpr int kBufF = RT * CW * K * 64;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
+
+  auto publish = [&](float xv, int g, int buf) {
+    float phi[K];
+    int s;
+    phi_of_x<N, K>(xv, 2 * (g * CW + cw) + h < sh.I, sh, tab, dc, phi, s);
+#pragma unroll
+    for (int k = 0; k < K; ++k) my_phi[buf * kBufF + (cw * K + k) * 64 + lane] = phi[k];
+  };
+  auto wload = [&](int g, float (&w)[CW][K][NT]) {
+#pragma unroll
+    for (int p = 0; p < CW; ++p)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        bload<NT, VW>(rw, vw_off, (g * CW + p) * pair_w + k * rowb, w[p][k]);
+  };
+
+  float wA[CW][K][NT], wB[CW][K][NT];
+  publish(bload1(rx, vx_off, 0), 0, 0);
+  float xn = bload1(rx, vx_off, 8 * CW);  // group 1
+  wload(0, wA);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  auto group = [&](int g, const float (&w)[CW][K][NT], float (&wn)[CW][K][NT]) {
+    const int buf = g & 1;
+    wload(g + 1, wn);  // past the last input: reads return 0
+    const float xn2 = bload1(rx, vx_off, 8 * CW * (g + 2));
+    if (g + 1 < ngroup) publish(xn, g + 1, buf ^ 1);
+#pragma unroll
+    for (int p = 0; p < CW; ++p) {
+      float phi[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) phi[k] = my_phi[buf * kBufF + (p * K + k) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(phi[k], w[p][k][nt], acc[nt], 0, 0, 0);
+    }
+    xn = xn2;
+    __syncthreads();
+  };
+  int g = 0;
+  for (; g + 1 < ngroup; g += 2) {
+    group(g, wA, wB);
+    group(g + 1, wB, wA);
+  }
+  if (g < ngroup) group(g, wA, wB);
+
+  if (b0 >= sh.B) return;
+  const int oc = o0 + NT * r;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = b0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (row < sh.B) {
+      float* yp = y + (size_t)row * sh.O + oc;
+      if constexpr (VW >= 2) {
+        if (oc < sh.O)
+          *reinterpret_cast<float2*>(yp) =
+              make_float2(acc[0][q] * sh.out_scale, acc[1][q] * sh.out_scale);
+      } else {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+          if (oc + m < sh.O) yp[m] = acc[m][q] * sh.out_scale;
+      }
+    }
+  }
+}
+
+template <int N, int K, int CW, int RT>
+__global__ __launch_bounds__(64 * CW * RT) void pp_fwd_dense_shared_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ wt,
+                                                                  float* __restrict__ y, PPShape sh,
+                                                                  BasisTab tab, DenseCoord dc,
+                                                                  int vw) {
+  __shared__ float phil[2 * CW * RT * K * 64];
+  if (vw >= 2) fwd_dense_shared_body<N, K, CW, RT, 2>(x, wt, y, sh, tab, dc, phil);
+  else fwd_dense_shared_body<N, K, CW, RT, 1>(x, wt, y, sh, tab, dc, phil);
+}
+
+// ---------------------------------------------------------------------------
 // backward-input: block tile = 128 rows x 32 inputs (wave = 32 rows), K
 // accumulator tiles (one per weight index k).  The reduction runs over `out` in
 // chunks of 32: the W tile [K][32 inputs][32 outs] of the NEXT chunk is fetched
@@ -354,7 +490,7 @@ __device__ __forceinline__ void bwd_input_dense_body(const float* __restrict__ x
         dense_seg_xi(xv, sh, dc, s, xi);
         float l[N], dl[N], dphi[K];
         pp_lagrange_d<N>(xi, tab, l, dl);
-        expand_basis<N, K>(dl, s * sh.stride, dphi);
+        expand_basis<N, K>(dl, s, dphi);
         float gsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) gsum = fmaf(dphi[k], acc[k][q], gsum);
@@ -549,7 +685,10 @@ bool pp_dense_supported(const PPShape& sh) {
   if ((long)sh.B * sh.I * 4 >= lim || (long)sh.B * sh.O * 4 >= lim ||
       (long)sh.I * sh.K * sh.O * 4 >= lim)
     return false;
-#define X(N_, K_) if (sh.n == N_ && sh.K == K_) return true;
+#define X(N_, K_)                                            \
+  if (sh.n == N_ && sh.K == K_)                               \
+    return sh.S == DenseGeom<N_, K_>::S &&                    \
+           (sh.S == 1 || sh.stride == DenseGeom<N_, K_>::stride);
   PP_DENSE_COMBOS(X)
 #undef X
   return false;
@@ -566,6 +705,27 @@ hipError_t pp_launch_fwd_dense(const float* x, const float* wt, float* y, int32_
   const DenseCoord dc = make_coord(sh);
   const int vw = vec_width(sh.O);
   const int nt = env_int("PP_DENSE_FWD_NT", sh.O > 64 ? 4 : 2);
+  const int shared = env_int("PP_DENSE_FWD_SHARED", sh.O > 64 ? 1 : 0);
+  if (shared) {
+    const int cw = sh.O > 128 ? 4 : 2;
+    const int rtl = cw == 4 ? 1 : 2;  // 256-thread blocks: several per CU, barriers decoupled
+    dim3 sgrid((sh.B + 32 * rtl - 1) / (32 * rtl), (sh.O + 64 * cw - 1) / (64 * cw));
+#define X(N_, K_)                                                                               \
+  if (sh.n == N_ && sh.K == K_) {                                                               \
+    if (cw == 4)                                                                                \
+      hipLaunchKernelGGL((pp_fwd_dense_shared_kernel<N_, K_, 4, 1>), sgrid, dim3(256), 0, st, x, \
+                         wt, y, sh, tab, dc, vw);                                                   \
+    else                                                                                        \
+      hipLaunchKernelGGL((pp_fwd_dense_shared_kernel<N_, K_, 2, 2>), sgrid, dim3(256), 0, st, x, \
+                         wt, y, sh, tab, dc, vw);                                                   \
+    hipError_t e = hipGetLastError();                                                           \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                      \
+    return e;                                                                                   \
+  }
+    PP_DENSE_COMBOS(X)
+#undef X
+    return hipErrorInvalidValue;
+  }
   dim3 grid((sh.B + 127) / 128, (sh.O + 32 * nt - 1) / (32 * nt));
 #define X(N_, K_)                                                                                 \
   if (sh.n == N_ && sh.K == K_) {                                                                 \

@@ -117,13 +117,26 @@ __global__ __launch_bounds__(256) void pp_sort_pass_kernel(const float* __restri
 }
 
 // K2: per bucket, exclusive prefix over the row chunks (in place) and the total.
+// Thread per bucket (coalesced across buckets); the chunk loads are issued eight
+// at a time so the loop is not one dependent L2 round trip per chunk.
 __global__ __launch_bounds__(256) void pp_sort_prefix_kernel(int* __restrict__ counts,
                                                              int* __restrict__ totals, int NB,
                                                              int nrc) {
   const int bkt = blockIdx.x * 256 + threadIdx.x;
   if (bkt >= NB) return;
   int run = 0;
-  for (int rc = 0; rc < nrc; ++rc) {
+  int rc = 0;
+  for (; rc + 8 <= nrc; rc += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = counts[(size_t)(rc + u) * NB + bkt];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      counts[(size_t)(rc + u) * NB + bkt] = run;
+      run += v[u];
+    }
+  }
+  for (; rc < nrc; ++rc) {
     const size_t idx = (size_t)rc * NB + bkt;
     const int v = counts[idx];
     counts[idx] = run;
