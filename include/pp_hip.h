@@ -65,6 +65,8 @@ enum {
   PP_METHOD_AUTO = 0,
   PP_FWD_GATHER = 1,  /* wavefront-cooperative gather of the active slab (any S) */
   PP_FWD_DENSE = 2,   /* expanded-basis x weight on f32 MFMA (small K only) */
+  PP_FWD_BF16X3 = 3,  /* same contraction on bf16 MFMA, operands split 3-way (fp32-level accuracy);
+                         needs a workspace: pp_forward_ws_f32 */
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
@@ -92,6 +94,15 @@ int pp_segment_ids_f32(const float* x, int32_t* seg, int B, int I, int S, float 
 int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
                    int O, int n, int S, int discontinuous, float length, const float* nodes,
                    float out_scale, int method, void* stream);
+
+/* Same as pp_forward_f32 with caller-owned scratch (pp_forward_workspace_bytes; may be
+ * NULL/0 for methods that need none).  PP_METHOD_AUTO may pick a workspace method
+ * only through this entry point. */
+size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method);
+int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
+                      void* workspace, size_t workspace_bytes, int B, int I, int O, int n, int S,
+                      int discontinuous, float length, const float* nodes, float out_scale,
+                      int method, void* stream);
 
 /* Backward w.r.t. the input (A4' of SURVEY.md 8(a)):
  * gx[b,i] = out_scale * (L/(x_max-x_min)) * sum_o gy[b,o] * sum_j l'_j(xi) * w_t[i, s*stride+j, o].

@@ -1,0 +1,316 @@
+// Dense path on the bf16 matrix cores with a 3-way operand split ("bf16x3").
+//
+// The f32-input MFMA runs at the fp32 vector rate (157 TFLOP/s); the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) is 16x faster per k-value.  An fp32 value splits
+// EXACTLY into three bf16 pieces (a = a1 + a2 + a3, 8 significant bits each, by
+// truncation and exact residuals), every bf16 x bf16 product is exact in the
+// MFMA's fp32 accumulator, and the six leading cross terms
+//     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1
+// reproduce the fp32 product to ~2^-23 relative (dropped: a2b3, a3b2, a3b3).  Six
+// bf16 MFMAs per k-step cost 6/16 of one f32 MFMA step: 2.7x the fp32 matrix rate
+// at fp32-level accuracy (the parity bar is 1e-5 relative; measured error ~1e-7).
+//
+// forward  y[b,o] = sum_{i,k} Phi[b,i,k] * w_t[i,k,o]
+//   k-dimension ordered (k, i): one MFMA k-step = 16 consecutive inputs at a fixed
+//   weight index k, so a lane evaluates the basis of an input once and uses its K
+//   columns in K different k-steps.  Block = 4 waves = 4 column tiles (64 outs each)
+//   of one 32-row tile; per step of 16 inputs every wave evaluates and splits the
+//   basis of 2 inputs per lane and publishes it in LDS ([plane][k][half][row] x 16 B,
+//   conflict-free ds_read_b128); weights come pre-split from a packed buffer
+//   P[plane][k][step][out][16 inputs] (coalesced 16-byte loads), written once per
+//   call by pp_bf3_pack_w_kernel.
+#include <algorithm>
+#include <type_traits>
+
+#include "pp_device.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+struct DenseCoord3 {
+  float w2, inv_w, inv_len;
+};
+
+__device__ __forceinline__ rsrc_t make_rsrc3(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// a = p1 + p2 + p3 exactly (up to 2^-24 |a|); each piece has <= 8 significant bits
+// (its low 16 bits are zero), returned as raw fp32 bit patterns.
+__device__ __forceinline__ void split3(float a, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(p1);
+  p2 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(p2);
+  p3 = __float_as_uint(r2) & 0xffff0000u;
+}
+
+template <int N, int K>
+struct Geom3 {
+  static constexpr bool disc = (K % N == 0) && (((K / N) & (K / N - 1)) == 0);
+  static constexpr int stride = disc ? N : N - 1;
+  static constexpr int S = disc ? K / N : (N > 1 ? (K - 1) / (N - 1) : K);
+};
+
+template <int N, int K>
+__device__ __forceinline__ void phi3(float x, bool valid, const PPShape& sh, const BasisTab& tab,
+                                     const DenseCoord3& dc, float (&phi)[K]) {
+  const float t = ((x + sh.half) * dc.inv_len) * sh.Sf;
+  const float tc = __builtin_amdgcn_fmed3f(t, -1.0f, sh.Sf);
+  int si = (int)tc;
+  si = min(max(si, 0), sh.S - 1);
+  const int s = (__builtin_fabsf(t) < 9.2e18f) ? si : 0;
+  const float x_min = (float)s * dc.w2 - 1.0f;
+  const float xi = sh.length * ((x - x_min) * dc.inv_w) - sh.half;
+  float l[N];
+  pp_lagrange<N>(xi, tab, l);
+  constexpr int S = Geom3<N, K>::S, stride = Geom3<N, K>::stride;
+  bool is[S];
+#pragma unroll
+  for (int q = 0; q < S; ++q) is[q] = valid && (s == q);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int j = k - q * stride;
+      if (j >= 0 && j < N) v = is[q] ? l[j] : v;
+    }
+    phi[k] = v;
+  }
+}
+
+// P[plane][k][step][out][16]: bf16 pieces of w_t[i = 16*step + j][k][out]
+__global__ __launch_bounds__(256) void pp_bf3_pack_w_kernel(const float* __restrict__ wt,
+                                                            unsigned short* __restrict__ P, int I,
+                                                            int K, int O, int nstep) {
+  const long per_plane = (long)K * nstep * O * 16;
+  long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stepg = (long)gridDim.x * 256;
+  for (; e < per_plane; e += stepg) {
+    const int j = (int)(e & 15);
+    long q = e >> 4;
+    const int o = (int)(q % O);
+    q /= O;
+    const int s = (int)(q % nstep);
+    const int k = (int)(q / nstep);
+    const int i = 16 * s + j;
+    const float v = i < I ? wt[((size_t)i * K + k) * O + o] : 0.0f;
+    unsigned p1, p2, p3;
+    split3(v, p1, p2, p3);
+    P[e] = (unsigned short)(p1 >> 16);
+    P[per_plane + e] = (unsigned short)(p2 >> 16);
+    P[2 * per_plane + e] = (unsigned short)(p3 >> 16);
+  }
+}
+
+template <int N, int K, int RM>
+__global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict__ x,
+                                                         const void* __restrict__ P,
+                                                         float* __restrict__ y, PPShape sh,
+                                                         BasisTab tab, DenseCoord3 dc, int nstep) {
+  // block = 4 waves = 4 column tiles (64 outs each) x one tile of 32*RM rows; every
+  // W fragment a wave loads feeds RM row tiles (W-fragment traffic per MFMA / RM)
+  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [2][3][K][2][32*RM] x 16 B
+  constexpr int ROWS = 32 * RM;
+  constexpr int kBufU = 3 * K * 2 * ROWS;
+  const int lane = threadIdx.x & 63;
+  const int cw = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b0 = blockIdx.x * ROWS;
+  const int o0 = (blockIdx.y * 4 + cw) * 64;
+  // producer role: inputs 16*s + 8*hb + ipos, +1 of rows b0 + r + 32*rm
+  const int hb = cw >> 1, ipos = 4 * (cw & 1) + 2 * h;
+  const rsrc_t rx = make_rsrc3(x, (unsigned)sh.B * sh.I * 4u);
+  int vx_off[RM];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+    vx_off[rm] = (min(b0 + rm * 32 + r, sh.B - 1) * sh.I + 8 * hb + ipos) * 4;
+  unsigned* phiW = reinterpret_cast<unsigned*>(phiL);
+  // consumer role
+  const rsrc_t rp = make_rsrc3(P, (unsigned)(3u * K * nstep * sh.O * 32u));
+  int vcol[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) vcol[nt] = (min(o0 + nt * 32 + r, sh.O - 1) * 2 + h) * 16;
+  const int step_bytes = sh.O * 32;        // one (plane, k, step) slab
+  const int k_bytes = nstep * step_bytes;  // one (plane, k)
+  const int plane_bytes = K * k_bytes;
+
+  f32x16 acc[RM][2];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[rm][nt][q] = 0.0f;
+
+  auto xload = [&](int s, float (&xv)[RM][2]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      xv[rm][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx_off[rm], 64 * s, 0));
+      xv[rm][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx_off[rm] + 4, 64 * s, 0));
+    }
+  };
+  auto produce = [&](int s, int buf, const float (&xv)[RM][2]) {
+    const int i0 = 16 * s + 8 * hb + ipos;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      float pa[K], pb[K];
+      phi3<N, K>(xv[rm][0], i0 < sh.I, sh, tab, dc, pa);
+      phi3<N, K>(xv[rm][1], i0 + 1 < sh.I, sh, tab, dc, pb);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        unsigned a1, a2, a3, c1, c2, c3;
+        split3(pa[k], a1, a2, a3);
+        split3(pb[k], c1, c2, c3);
+        const int base = (buf * kBufU + (k * 2 + hb) * ROWS + rm * 32 + r) * 4 + (ipos >> 1);
+        phiW[base] = (a1 >> 16) | c1;
+        phiW[base + K * 2 * ROWS * 4] = (a2 >> 16) | c2;
+        phiW[base + 2 * K * 2 * ROWS * 4] = (a3 >> 16) | c3;
+      }
+    }
+  };
+  auto wload = [&](int s, int k, bf16x8 (&w)[3][2]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        w[p][nt] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rp, vcol[nt], p * plane_bytes + k * k_bytes + s * step_bytes, 0));
+  };
+  auto aload = [&](int buf, int k, bf16x8 (&a)[RM][3]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[rm][p] = __builtin_bit_cast(
+            bf16x8, phiL[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
+  };
+  auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[3][2]) {
+    // the six leading cross terms, small ones first, a1*b1 last
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[rm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm][PA[c]], w[PB[c]][nt],
+                                                                acc[rm][nt], 0, 0, 0);
+  };
+
+  float xv[RM][2], xn[RM][2];
+  xload(0, xv);
+  produce(0, 0, xv);
+  xload(1, xv);
+  // two fragment sets in ping-pong over the flattened (step, k) sequence: the W loads
+  // of k-step q+1 are in flight, and its A fragments are read, under the MFMAs of q
+  bf16x8 W[2][3][2], A[2][RM][3];
+  wload(0, 0, W[0]);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  auto stepfn = [&](int s, auto par) {
+    constexpr int P0 = decltype(par)::value;
+    const int buf = s & 1;
+    xload(s + 2, xn);
+    aload(buf, 0, A[P0 & 1]);
+    if (s + 1 < nstep) produce(s + 1, buf ^ 1, xv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int cur = (k + P0) & 1, nxt = cur ^ 1;
+      if (k + 1 < K) {
+        wload(s, k + 1, W[nxt]);
+        aload(buf, k + 1, A[nxt]);
+      } else {
+        wload(s + 1, 0, W[nxt]);
+      }
+      mm(A[cur], W[cur]);
+    }
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      xv[rm][0] = xn[rm][0];
+      xv[rm][1] = xn[rm][1];
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < nstep; s += 2) {
+    stepfn(s, std::integral_constant<int, 0>{});
+    if (s + 1 < nstep) stepfn(s + 1, std::integral_constant<int, (K & 1)>{});
+  }
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = o0 + nt * 32 + r;
+      if (col < sh.O) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (row < sh.B) y[(size_t)row * sh.O + col] = acc[rm][nt][q] * sh.out_scale;
+        }
+      }
+    }
+}
+
+#define PP_BF3_COMBOS(X) \
+  X(1, 1) X(1, 2) X(1, 4) X(1, 8) \
+  X(2, 2) X(2, 3) X(2, 4) X(2, 5) X(2, 8) \
+  X(3, 3) X(3, 5) X(3, 6) X(4, 4) X(4, 7) X(4, 8) \
+  X(5, 5) X(6, 6) X(7, 7) X(8, 8)
+
+int nstep_of(const PPShape& sh) { return (sh.I + 15) / 16; }
+
+}  // namespace
+
+bool pp_bf3_supported(const PPShape& sh) {
+  if (!pp_dense_supported(sh)) return false;
+  return (long)3 * sh.K * nstep_of(sh) * sh.O * 32 < (1L << 31);
+}
+
+size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
+  return (size_t)3 * sh.K * nstep_of(sh) * sh.O * 32;
+}
+
+hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                             const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  const int nstep = nstep_of(sh);
+  DenseCoord3 dc;
+  dc.w2 = 2.0f / (float)sh.S;
+  dc.inv_w = (float)sh.S / 2.0f;
+  dc.inv_len = 1.0f / sh.length;
+  const long per_plane = (long)sh.K * nstep * sh.O * 16;
+  const int pblocks = (int)std::min<long>((per_plane + 255) / 256, 4096);
+  hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3(pblocks), dim3(256), 0, st, wt,
+                     static_cast<unsigned short*>(ws), sh.I, sh.K, sh.O, nstep);
+  const int rm = sh.B >= 8192 ? 2 : 1;
+  dim3 grid((sh.B + 32 * rm - 1) / (32 * rm), (sh.O + 255) / 256);
+#define X(N_, K_)                                                                              \
+  if (sh.n == N_ && sh.K == K_) {                                                              \
+    const size_t lds = (size_t)2 * 3 * K_ * 2 * 32 * rm * 16;                                  \
+    if (rm == 2) {                                                                             \
+      static bool once = false;                                                                \
+      if (!once && lds > 48 * 1024) {                                                          \
+        (void)hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<N_, K_, 2>,                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        once = true;                                                                           \
+      }                                                                                        \
+      hipLaunchKernelGGL((pp_fwd_bf3_kernel<N_, K_, 2>), grid, dim3(256), lds, st, x,          \
+                         (const void*)ws, y, sh, tab, dc, nstep);                              \
+    } else {                                                                                   \
+      hipLaunchKernelGGL((pp_fwd_bf3_kernel<N_, K_, 1>), grid, dim3(256), lds, st, x,          \
+                         (const void*)ws, y, sh, tab, dc, nstep);                              \
+    }                                                                                          \
+    hipError_t e = hipGetLastError();                                                          \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                     \
+    return e;                                                                                  \
+  }
+  PP_BF3_COMBOS(X)
+#undef X
+  return hipErrorInvalidValue;
+}

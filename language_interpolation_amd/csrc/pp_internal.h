@@ -52,3 +52,9 @@ hipError_t pp_launch_layer_norm_bwd(const float* y, const float* gy, const float
 hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float eps, hipStream_t st);
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
+
+// ---- dense path on bf16 MFMA with a 3-way fp32 split (pp_bf3.hip) ----
+bool pp_bf3_supported(const PPShape& sh);
+size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);
+hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                             const PPShape& sh, const BasisTab& tab, hipStream_t st);

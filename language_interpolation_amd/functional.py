@@ -103,12 +103,16 @@ def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False):
     seg = torch.empty(B, I, device=x.device, dtype=torch.int32) if want_seg else None
     if B == 0:
         return y, seg
+    method = _lib.FWD_METHODS[spec.fwd_method]
+    nbytes = lib.pp_forward_workspace_bytes(B, I, O, spec.n, spec.segments,
+                                            int(spec.discontinuous), method)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
-        rc = lib.pp_forward_f32(
-            _ptr(x), _ptr(w_t), _ptr(y), _ptr(seg), B, I, O, spec.n, spec.segments,
-            int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale,
-            _lib.FWD_METHODS[spec.fwd_method], _stream(x.device))
-    _lib.check(rc, "pp_forward_f32")
+        rc = lib.pp_forward_ws_f32(
+            _ptr(x), _ptr(w_t), _ptr(y), _ptr(seg), _ptr(ws), nbytes, B, I, O, spec.n,
+            spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
+            spec.out_scale, method, _stream(x.device))
+    _lib.check(rc, "pp_forward_ws_f32")
     return y, seg
 
 

@@ -115,6 +115,17 @@ def test_dense_mfma_methods(case):
         check(got3, ref3, "dense/length4")
 
 
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16x3_forward(case):
+    """bf16 matrix cores with 3-way split operands: same 1e-5 bar as the fp32 kernels."""
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=7)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc, "bf16x3", "dense", "dense")
+    check(got, ref, "bf16x3")
+    print("bf16x3 y rel err", rel_err(got["y"], ref["y"]))
+
+
 def test_dense_rejects_inexact_layers():
     """S or length not a power of two -> the dense kernels refuse (gather path serves them)."""
     from language_interpolation_amd._lib import PPHipError
