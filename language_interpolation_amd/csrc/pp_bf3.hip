@@ -108,18 +108,27 @@ __global__ __launch_bounds__(256) void pp_bf3_pack_w_kernel(const float* __restr
   }
 }
 
-template <int N, int K, int RM>
-__global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict__ x,
-                                                         const void* __restrict__ P,
-                                                         float* __restrict__ y, PPShape sh,
-                                                         BasisTab tab, DenseCoord3 dc, int nstep) {
-  // block = 4 waves = 4 column tiles (64 outs each) x one tile of 32*RM rows; every
-  // W fragment a wave loads feeds RM row tiles (W-fragment traffic per MFMA / RM)
-  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [2][3][K][2][32*RM] x 16 B
+template <int N, int K, int RM, int G>
+__global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __restrict__ x,
+                                                             const void* __restrict__ P,
+                                                             float* __restrict__ y, PPShape sh,
+                                                             BasisTab tab, DenseCoord3 dc,
+                                                             int nstep) {
+  // block = G groups of 4 waves.  A group = 4 column tiles (64 outs each) x one tile of
+  // 32*RM rows; every W fragment a wave loads feeds RM row tiles.  With G = 2 the two
+  // groups take alternate 16-input steps of the SAME output tile (split-k inside the
+  // block, two waves per SIMD: one group's waits and basis evaluation sit under the
+  // other's MFMAs) and add their accumulators through LDS at the end.  nstep is a
+  // multiple of G (the packed weights are zero-padded to it).
+  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [G][2][3][K][2][32*RM] x 16 B
   constexpr int ROWS = 32 * RM;
   constexpr int kBufU = 3 * K * 2 * ROWS;
   const int lane = threadIdx.x & 63;
-  const int cw = threadIdx.x >> 6;
+  // wave-uniform ids in SGPRs (a VGPR step offset would turn every buffer load into a
+  // readfirstlane loop)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cw = wv & 3;
+  const int g = G > 1 ? wv >> 2 : 0;
   const int r = lane & 31, h = lane >> 5;
   const int b0 = blockIdx.x * ROWS;
   const int o0 = (blockIdx.y * 4 + cw) * 64;
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
 #pragma unroll
   for (int rm = 0; rm < RM; ++rm)
     vx_off[rm] = (min(b0 + rm * 32 + r, sh.B - 1) * sh.I + 8 * hb + ipos) * 4;
-  unsigned* phiW = reinterpret_cast<unsigned*>(phiL);
+  u32x4* phiG = phiL + g * 2 * kBufU;
+  unsigned* phiW = reinterpret_cast<unsigned*>(phiG);
   // consumer role
   const rsrc_t rp = make_rsrc3(P, (unsigned)(3u * K * nstep * sh.O * 32u));
   int vcol[2];
@@ -148,6 +158,7 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[rm][nt][q] = 0.0f;
 
+  // s: global step index (16 inputs); t: this group's iteration, s = t*G + g
   auto xload = [&](int s, float (&xv)[RM][2]) {
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         a[rm][p] = __builtin_bit_cast(
-            bf16x8, phiL[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
+            bf16x8, phiG[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
   };
   auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[3][2]) {
     // the six leading cross terms, small ones first, a1*b1 last
@@ -205,22 +216,24 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
                                                                 acc[rm][nt], 0, 0, 0);
   };
 
+  const int T = nstep / G;
   float xv[RM][2], xn[RM][2];
-  xload(0, xv);
-  produce(0, 0, xv);
-  xload(1, xv);
+  xload(g, xv);
+  produce(g, 0, xv);
+  xload(G + g, xv);
   // two fragment sets in ping-pong over the flattened (step, k) sequence: the W loads
   // of k-step q+1 are in flight, and its A fragments are read, under the MFMAs of q
   bf16x8 W[2][3][2], A[2][RM][3];
-  wload(0, 0, W[0]);
+  wload(g, 0, W[0]);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  auto stepfn = [&](int s, auto par) {
+  auto stepfn = [&](int t, auto par) {
     constexpr int P0 = decltype(par)::value;
-    const int buf = s & 1;
-    xload(s + 2, xn);
+    const int buf = t & 1;
+    const int s = t * G + g;
+    xload(s + 2 * G, xn);
     aload(buf, 0, A[P0 & 1]);
-    if (s + 1 < nstep) produce(s + 1, buf ^ 1, xv);
+    if (t + 1 < T) produce(s + G, buf ^ 1, xv);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int cur = (k + P0) & 1, nxt = cur ^ 1;
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
         wload(s, k + 1, W[nxt]);
         aload(buf, k + 1, A[nxt]);
       } else {
-        wload(s + 1, 0, W[nxt]);
+        wload(s + G, 0, W[nxt]);
       }
       mm(A[cur], W[cur]);
     }
@@ -239,23 +252,47 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
     }
     __syncthreads();
   };
-  for (int s = 0; s < nstep; s += 2) {
-    stepfn(s, std::integral_constant<int, 0>{});
-    if (s + 1 < nstep) stepfn(s + 1, std::integral_constant<int, (K & 1)>{});
+  for (int t = 0; t < T; t += 2) {
+    stepfn(t, std::integral_constant<int, 0>{});
+    if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{});
   }
+
+  auto store_nt = [&](auto ntc, const float* part) {
+    constexpr int nt = decltype(ntc)::value;
+    const int col = o0 + nt * 32 + r;
 #pragma unroll
-  for (int rm = 0; rm < RM; ++rm)
+    for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = o0 + nt * 32 + r;
-      if (col < sh.O) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          if (row < sh.B) y[(size_t)row * sh.O + col] = acc[rm][nt][q] * sh.out_scale;
-        }
+      for (int q = 0; q < 16; ++q) {
+        const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        float v = acc[rm][nt][q];
+        if (part) v += part[(rm * 16 + q) * 64];
+        if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = v * sh.out_scale;
       }
-    }
+  };
+  if (G == 1) {
+    store_nt(std::integral_constant<int, 0>{}, nullptr);
+    store_nt(std::integral_constant<int, 1>{}, nullptr);
+  } else {
+    // group g finishes column half nt = g of its wave's tile: hand the other half to
+    // the partner wave (same cw, other group) through LDS (the basis buffers are free:
+    // the loop ended on a barrier)
+    float* red = reinterpret_cast<float*>(phiL);  // [g][cw][RM*16][64]
+    float* mine = red + ((g * 4 + cw) * RM * 16) * 64 + lane;
+    const float* theirs = red + (((g ^ 1) * 4 + cw) * RM * 16) * 64 + lane;
+    auto give = [&](auto ntc) {
+      constexpr int nt = decltype(ntc)::value;
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mine[(rm * 16 + q) * 64] = acc[rm][nt][q];
+    };
+    if (g == 0) give(std::integral_constant<int, 1>{});
+    else give(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (g == 0) store_nt(std::integral_constant<int, 0>{}, theirs);
+    else store_nt(std::integral_constant<int, 1>{}, theirs);
+  }
 }
 
 #define PP_BF3_COMBOS(X) \
@@ -264,10 +301,31 @@ __global__ __launch_bounds__(256) void pp_fwd_bf3_kernel(const float* __restrict
   X(3, 3) X(3, 5) X(3, 6) X(4, 4) X(4, 7) X(4, 8) \
   X(5, 5) X(6, 6) X(7, 7) X(8, 8)
 
-int nstep_of(const PPShape& sh) { return (sh.I + 15) / 16; }
+// 16-input steps, padded to even so the two-group kernel splits them evenly
+int nstep_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 2; }
+
+template <int N, int K, int RM, int G>
+hipError_t launch_bf3(const float* x, const void* ws, float* y, const PPShape& sh,
+                      const BasisTab& tab, const DenseCoord3& dc, int nstep, hipStream_t st) {
+  size_t lds = (size_t)G * 2 * 3 * K * 2 * 32 * RM * 16;
+  if (G == 2) lds = std::max(lds, (size_t)2 * 4 * RM * 16 * 64 * 4);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    static bool once = false;  // per instantiation
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<N, K, RM, G>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      once = true;
+    }
+  }
+  dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 255) / 256);
+  hipLaunchKernelGGL((pp_fwd_bf3_kernel<N, K, RM, G>), grid, dim3(256 * G), lds, st, x, ws, y, sh,
+                     tab, dc, nstep);
+  return hipGetLastError();
+}
 
 }  // namespace
-
 bool pp_bf3_supported(const PPShape& sh) {
   if (!pp_dense_supported(sh)) return false;
   return (long)3 * sh.K * nstep_of(sh) * sh.O * 32 < (1L << 31);
@@ -288,27 +346,26 @@ hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t*
   const int pblocks = (int)std::min<long>((per_plane + 255) / 256, 4096);
   hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3(pblocks), dim3(256), 0, st, wt,
                      static_cast<unsigned short*>(ws), sh.I, sh.K, sh.O, nstep);
-  const int rm = sh.B >= 8192 ? 2 : 1;
-  dim3 grid((sh.B + 32 * rm - 1) / (32 * rm), (sh.O + 255) / 256);
-#define X(N_, K_)                                                                              \
-  if (sh.n == N_ && sh.K == K_) {                                                              \
-    const size_t lds = (size_t)2 * 3 * K_ * 2 * 32 * rm * 16;                                  \
-    if (rm == 2) {                                                                             \
-      static bool once = false;                                                                \
-      if (!once && lds > 48 * 1024) {                                                          \
-        (void)hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<N_, K_, 2>,                   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-        once = true;                                                                           \
-      }                                                                                        \
-      hipLaunchKernelGGL((pp_fwd_bf3_kernel<N_, K_, 2>), grid, dim3(256), lds, st, x,          \
-                         (const void*)ws, y, sh, tab, dc, nstep);                              \
-    } else {                                                                                   \
-      hipLaunchKernelGGL((pp_fwd_bf3_kernel<N_, K_, 1>), grid, dim3(256), lds, st, x,          \
-                         (const void*)ws, y, sh, tab, dc, nstep);                              \
-    }                                                                                          \
-    hipError_t e = hipGetLastError();                                                          \
-    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                     \
-    return e;                                                                                  \
+  // variant: 64-row tiles once they fill the chip; two wave groups (split-k in the
+  // block) when their basis buffers fit LDS.  PP_BF3_VARIANT=<rm><g> overrides (tuning).
+  int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
+  int grp = (size_t)2 * 2 * 3 * sh.K * 2 * 32 * rm * 16 <= 160 * 1024 ? 2 : 1;
+  if (const char* v = getenv("PP_BF3_VARIANT")) {
+    const int code = atoi(v);
+    if (code / 10 >= 1 && code / 10 <= 2 && code % 10 >= 1 && code % 10 <= 2) {
+      rm = code / 10;
+      grp = code % 10;
+    }
+  }
+#define X(N_, K_)                                                                          \
+  if (sh.n == N_ && sh.K == K_) {                                                          \
+    hipError_t e;                                                                          \
+    if (rm == 2 && grp == 2) e = launch_bf3<N_, K_, 2, 2>(x, ws, y, sh, tab, dc, nstep, st); \
+    else if (rm == 2) e = launch_bf3<N_, K_, 2, 1>(x, ws, y, sh, tab, dc, nstep, st);      \
+    else if (grp == 2) e = launch_bf3<N_, K_, 1, 2>(x, ws, y, sh, tab, dc, nstep, st);     \
+    else e = launch_bf3<N_, K_, 1, 1>(x, ws, y, sh, tab, dc, nstep, st);                   \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                 \
+    return e;                                                                              \
   }
   PP_BF3_COMBOS(X)
 #undef X
