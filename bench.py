@@ -82,26 +82,38 @@ def roofline_for_hidden_layer(B, dev):
     gw = torch.empty(I, K, O, device=dev)
     nbytes = lib.pp_workspace_bytes(B, I, O, n, S, 0, 0)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    fbytes = lib.pp_forward_workspace_bytes(B, I, O, n, S, 0, 0)
+    fws = torch.empty(max(fbytes, 16), dtype=torch.uint8, device=dev)
+    xbytes = lib.pp_backward_input_workspace_bytes(B, I, O, n, S, 0, 0)
+    xws = torch.empty(max(xbytes, 16), dtype=torch.uint8, device=dev)
     nodes = spec.node_array()
     st = PF._stream(dev)
     P = PF._ptr
 
+    # the same entry points, methods (auto) and workspaces the module's autograd function uses
     def fwd():
-        lib.pp_forward_f32(P(x), P(w_t), P(y), None, B, I, O, n, S, 0, 2.0, nodes, 1.0, 0, st)
+        lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(fws), fbytes, B, I, O, n, S, 0, 2.0,
+                              nodes, 1.0, 0, st)
 
     def bwd_x():
-        lib.pp_backward_input_f32(P(x), P(gy), P(w_t), P(gx), B, I, O, n, S, 0, 2.0, nodes, 1.0, 0, st)
+        lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(xws), xbytes, B, I, O, n, S, 0,
+                                     2.0, nodes, 1.0, 0, st)
 
     def bwd_w():
         lib.pp_backward_weight_f32(P(x), P(gy), P(gw), P(ws), nbytes, B, I, O, n, S, 0, 2.0, nodes,
                                    1.0, 0, st)
 
-    times = {"pp_fwd_dense_kernel": time_kernel(fwd), "pp_bwd_input_dense_kernel": time_kernel(bwd_x),
-             "pp_bwd_weight_dense_kernel(+reduce)": time_kernel(bwd_w)}
+    methods = [lib.pp_auto_method(p, B, I, O, n, S, 0) for p in range(3)]
+    fname = {1: "pp_fwd_gather_kernel", 2: "pp_fwd_dense_kernel",
+             3: "pp_fwd_bf3_kernel(+pack)"}[methods[0]]
+    xname = {1: "pp_bwd_input_gather_kernel", 2: "pp_bwd_input_dense_kernel",
+             3: "pp_bwd_x_bf3_kernel(+pack)"}[methods[1]]
+    wname = {1: "pp_bwd_weight_atomic_kernel", 2: "pp_bwd_weight_segreduce_kernel(+sort)",
+             3: "pp_bwd_weight_dense_kernel(+reduce)"}[methods[2]]
+    times = {fname: time_kernel(fwd), xname: time_kernel(bwd_x), wname: time_kernel(bwd_w)}
     name = max(times, key=times.get)
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)
     achieved = flops / times[name] * 1e-12
-    methods = [lib.pp_auto_method(p, B, I, O, n, S, 0) for p in range(3)]
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,

@@ -71,7 +71,9 @@ enum {
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
   PP_BWD_X_GATHER = 1,
-  PP_BWD_X_DENSE = 2
+  PP_BWD_X_DENSE = 2,
+  PP_BWD_X_BF16X3 = 3 /* gy x w^T on bf16 MFMA, operands split 3-way; needs a workspace:
+                         pp_backward_input_ws_f32 */
 };
 
 /* Library version (major*10000 + minor*100 + patch). No reference counterpart. */
@@ -111,6 +113,16 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
 int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, float* gx, int B,
                           int I, int O, int n, int S, int discontinuous, float length,
                           const float* nodes, float out_scale, int method, void* stream);
+
+/* Same as pp_backward_input_f32 with caller-owned scratch (pp_backward_input_workspace_bytes;
+ * NULL/0 for methods that need none).  PP_METHOD_AUTO may pick a workspace method only
+ * through this entry point. */
+size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                         int method);
+int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
+                             void* workspace, size_t workspace_bytes, int B, int I, int O, int n,
+                             int S, int discontinuous, float length, const float* nodes,
+                             float out_scale, int method, void* stream);
 
 /* Bytes of scratch pp_backward_weight_f32 needs for `method` (0 for methods
  * that need none).  Scratch is caller-owned device memory, 16-byte aligned,

@@ -18,11 +18,11 @@ PP_MAX_N = 8
 # method ids (include/pp_hip.h)
 METHOD_AUTO = 0
 FWD_GATHER, FWD_DENSE, FWD_BF16X3 = 1, 2, 3
-BWD_X_GATHER, BWD_X_DENSE = 1, 2
+BWD_X_GATHER, BWD_X_DENSE, BWD_X_BF16X3 = 1, 2, 3
 BWD_W_ATOMIC, BWD_W_SORT, BWD_W_DENSE = 1, 2, 3
 
 FWD_METHODS = {"auto": 0, "gather": 1, "dense": 2, "bf16x3": 3}
-BWD_X_METHODS = {"auto": 0, "gather": 1, "dense": 2}
+BWD_X_METHODS = {"auto": 0, "gather": 1, "dense": 2, "bf16x3": 3}
 BWD_W_METHODS = {"auto": 0, "atomic": 1, "sort": 2, "dense": 3}
 
 # every symbol include/pp_hip.h declares: name -> (restype, argtypes)
@@ -45,6 +45,12 @@ SIGNATURES = {
     "pp_backward_input_f32": (
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
+    ),
+    "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 7),
+    "pp_backward_input_ws_f32": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
+         c_float, c_int, _P],
     ),
     "pp_workspace_bytes": (c_size_t, [c_int] * 7),
     "pp_backward_weight_f32": (

@@ -83,7 +83,8 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   switch (pass) {
     case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_BF16X3 : PP_FWD_DENSE)
                          : PP_FWD_GATHER;
-    case 1: return dense ? PP_BWD_X_DENSE : PP_BWD_X_GATHER;
+    case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_BF16X3 : PP_BWD_X_DENSE)
+                         : PP_BWD_X_GATHER;
     case 2:
       if (dense) return PP_BWD_W_DENSE;
       return pp_sort_supported(sh) ? PP_BWD_W_SORT : PP_BWD_W_ATOMIC;
@@ -152,17 +153,40 @@ int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
                            nodes, out_scale, method, stream);
 }
 
-int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, float* gx, int B,
-                          int I, int O, int n, int S, int discontinuous, float length,
-                          const float* nodes, float out_scale, int method, void* stream) {
+static int bwd_x_auto(const PPShape& sh, bool have_ws) {
+  if (!dense_preferred(sh)) return PP_BWD_X_GATHER;
+  if (have_ws && pp_bf3_bwd_x_supported(sh) && sh.B >= 256) return PP_BWD_X_BF16X3;
+  return PP_BWD_X_DENSE;
+}
+
+size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                         int method) {
+  PPShape sh;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (method == PP_METHOD_AUTO) method = bwd_x_auto(sh, true);
+  if (method == PP_BWD_X_BF16X3 && pp_bf3_bwd_x_supported(sh))
+    return pp_bf3_bwd_x_workspace_bytes(sh);
+  return 0;
+}
+
+int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
+                             void* workspace, size_t workspace_bytes, int B, int I, int O, int n,
+                             int S, int discontinuous, float length, const float* nodes,
+                             float out_scale, int method, void* stream) {
   if (!x || !gy || !w_t || !gx) return PP_ERR_NULL;
-  if (!aligned16(x) || !aligned16(gy) || !aligned16(w_t) || !aligned16(gx)) return PP_ERR_ALIGN;
+  if (!aligned16(x) || !aligned16(gy) || !aligned16(w_t) || !aligned16(gx) ||
+      !aligned16(workspace))
+    return PP_ERR_ALIGN;
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
   if (rc != PP_OK) return rc;
   BasisTab tab;
   make_basis(tab, n, length, nodes);
-  if (method == PP_METHOD_AUTO) method = dense_preferred(sh) ? PP_BWD_X_DENSE : PP_BWD_X_GATHER;
+  if (method == PP_METHOD_AUTO) {
+    method = bwd_x_auto(sh, workspace != nullptr);
+    if (method == PP_BWD_X_BF16X3 && workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh))
+      method = PP_BWD_X_DENSE;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (method == PP_BWD_X_GATHER)
     return hip_rc(pp_launch_bwd_input_gather(x, gy, w_t, gx, sh, tab, st));
@@ -170,7 +194,19 @@ int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, flo
     if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_bwd_input_dense(x, gy, w_t, gx, sh, tab, st));
   }
+  if (method == PP_BWD_X_BF16X3) {
+    if (!pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
+    if (!workspace || workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
+    return hip_rc(pp_launch_bwd_x_bf3(x, gy, w_t, gx, workspace, sh, tab, st));
+  }
   return PP_ERR_METHOD;
+}
+
+int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, float* gx, int B,
+                          int I, int O, int n, int S, int discontinuous, float length,
+                          const float* nodes, float out_scale, int method, void* stream) {
+  return pp_backward_input_ws_f32(x, gy, w_t, gx, nullptr, 0, B, I, O, n, S, discontinuous, length,
+                                  nodes, out_scale, method, stream);
 }
 
 size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method) {

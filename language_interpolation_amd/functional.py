@@ -123,12 +123,16 @@ def backward_input_raw(x, gy, w_t, spec: LayerSpec):
     gx = torch.empty_like(x)
     if B == 0:
         return gx
+    method = _lib.BWD_X_METHODS[spec.bwd_x_method]
+    nbytes = lib.pp_backward_input_workspace_bytes(B, I, O, spec.n, spec.segments,
+                                                   int(spec.discontinuous), method)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
-        rc = lib.pp_backward_input_f32(
-            _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), B, I, O, spec.n, spec.segments,
-            int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale,
-            _lib.BWD_X_METHODS[spec.bwd_x_method], _stream(x.device))
-    _lib.check(rc, "pp_backward_input_f32")
+        rc = lib.pp_backward_input_ws_f32(
+            _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), _ptr(ws), nbytes, B, I, O, spec.n,
+            spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
+            spec.out_scale, method, _stream(x.device))
+    _lib.check(rc, "pp_backward_input_ws_f32")
     return gx
 
 
