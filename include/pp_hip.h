@@ -70,6 +70,7 @@ enum {
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
+  PP_BWD_W_BF16X3 = 4, /* Phi^T x gy on bf16 MFMA, operands split 3-way (small K only) */
   PP_BWD_X_GATHER = 1,
   PP_BWD_X_DENSE = 2,
   PP_BWD_X_BF16X3 = 3 /* gy x w^T on bf16 MFMA, operands split 3-way; needs a workspace:

@@ -771,6 +771,21 @@ hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const floa
   return hipErrorInvalidValue;
 }
 
+// gwt[idx] = scale * sum_c part[c][idx], chunks added in a fixed order
+void pp_launch_chunk_reduce(const float* part, float* gwt, long total, int nchunk, float scale,
+                            hipStream_t st) {
+  if (total % 4 == 0) {
+    const long t4 = total / 4;
+    const int blocks = (int)std::min<long>((t4 + 255) / 256, 2048);
+    hipLaunchKernelGGL((pp_dense_reduce_kernel<float4>), dim3(blocks), dim3(256), 0, st,
+                       (const float4*)part, (float4*)gwt, t4, nchunk, scale);
+  } else {
+    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL((pp_dense_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, part, gwt,
+                       total, nchunk, scale);
+  }
+}
+
 hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gwt, void* ws,
                                       const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const DenseCoord dc = make_coord(sh);
@@ -794,16 +809,7 @@ hipError_t pp_launch_bwd_weight_dense(const float* x, const float* gy, float* gw
   if (!launched) return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || p.nchunk <= 1) return e;
-  const long total = (long)sh.I * sh.K * sh.O;
-  if (total % 4 == 0) {
-    const long t4 = total / 4;
-    const int blocks = (int)std::min<long>((t4 + 255) / 256, 2048);
-    hipLaunchKernelGGL((pp_dense_reduce_kernel<float4>), dim3(blocks), dim3(256), 0, st,
-                       (const float4*)ws, (float4*)gwt, t4, p.nchunk, sh.out_scale);
-  } else {
-    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL((pp_dense_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st,
-                       (const float*)ws, gwt, total, p.nchunk, sh.out_scale);
-  }
+  pp_launch_chunk_reduce(static_cast<const float*>(ws), gwt, (long)sh.I * sh.K * sh.O, p.nchunk,
+                         sh.out_scale, st);
   return hipGetLastError();
 }

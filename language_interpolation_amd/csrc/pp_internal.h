@@ -37,6 +37,8 @@ hipError_t pp_launch_bwd_weight_sort(const float* x, const float* gy, float* gwt
 // ---- dense f32-MFMA path (pp_dense.hip) ----
 bool pp_dense_supported(const PPShape& sh);
 size_t pp_dense_bwd_weight_workspace_bytes(const PPShape& sh);
+void pp_launch_chunk_reduce(const float* part, float* gwt, long total, int nchunk, float scale,
+                            hipStream_t st);
 hipError_t pp_launch_fwd_dense(const float* x, const float* wt, float* y, int32_t* seg,
                                const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const float* wt, float* gx,
@@ -62,3 +64,7 @@ bool pp_bf3_bwd_x_supported(const PPShape& sh);
 size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
                                void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st);
+bool pp_bf3_bwd_w_supported(const PPShape& sh);
+size_t pp_bf3_bwd_w_workspace_bytes(const PPShape& sh);
+hipError_t pp_launch_bwd_w_bf3(const float* x, const float* gy, float* gwt, void* ws,
+                               const PPShape& sh, const BasisTab& tab, hipStream_t st);

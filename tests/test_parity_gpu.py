@@ -141,11 +141,26 @@ def test_bf16x3_backward_input(case):
         check(got3, ref3, "bf16x3/length4")
 
 
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16x3_backward_weight(case):
+    """Phi^T x gy on the bf16 matrix cores (both operands split 3-way), 1e-5 bar."""
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=10)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc, "dense", "dense", "bf16x3")
+    check(got, ref, "bf16x3 bwd_w")
+    if dist == "normal" and not disc:
+        ref3 = oracle_all(x, w, gy, n, S, disc, length=4.0, rescale_output=True)
+        got3 = hip_all(x, w, gy, n, S, disc, "bf16x3", "bf16x3", "bf16x3", length=4.0,
+                       rescale_output=True)
+        check(got3, ref3, "bf16x3 all/length4")
+
+
 def test_bf16x3_backward_input_large_rows():
     """64-row tiles (B >= 4096) and a ragged last tile."""
     x, w, gy = make_inputs(4096 + 37, 250, 250, 3, 2, False, "normal", seed=9)
     ref = oracle_all(x, w, gy, 3, 2, False)
-    check(hip_all(x, w, gy, 3, 2, False, "bf16x3", "bf16x3", "dense"), ref, "bf16x3 large")
+    check(hip_all(x, w, gy, 3, 2, False, "bf16x3", "bf16x3", "bf16x3"), ref, "bf16x3 large")
 
 
 def test_dense_rejects_inexact_layers():
