@@ -85,27 +85,38 @@ __device__ __forceinline__ void phi3(float x, bool valid, const PPShape& sh, con
   }
 }
 
-// P[plane][k][step][out][16]: bf16 pieces of w_t[i = 16*step + j][k][out]
+// 8 fp32 pieces (low 16 bits zero) -> one 16-byte fragment of 8 bf16
+__device__ __forceinline__ u32x4 pack8(const unsigned* pc) {
+  u32x4 w;
+  w.x = (pc[0] >> 16) | pc[1];
+  w.y = (pc[2] >> 16) | pc[3];
+  w.z = (pc[4] >> 16) | pc[5];
+  w.w = (pc[6] >> 16) | pc[7];
+  return w;
+}
+
+// P[plane][k][step][out][16]: bf16 pieces of w_t[i = 16*step + j][k][out].  One thread
+// per (k, step, out): 16 reads coalesced over `out`, two 16-byte stores per plane.
 __global__ __launch_bounds__(256) void pp_bf3_pack_w_kernel(const float* __restrict__ wt,
-                                                            unsigned short* __restrict__ P, int I,
-                                                            int K, int O, int nstep) {
-  const long per_plane = (long)K * nstep * O * 16;
-  long e = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stepg = (long)gridDim.x * 256;
-  for (; e < per_plane; e += stepg) {
-    const int j = (int)(e & 15);
-    long q = e >> 4;
-    const int o = (int)(q % O);
-    q /= O;
-    const int s = (int)(q % nstep);
-    const int k = (int)(q / nstep);
+                                                            u32x4* __restrict__ P, int I, int K,
+                                                            int O, int nstep) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_plane = (long)K * nstep * O;  // in (k, step, out) slots of 32 bytes
+  if (id >= per_plane) return;
+  const int o = (int)(id % O);
+  const int s = (int)((id / O) % nstep);
+  const int k = (int)(id / ((long)O * nstep));
+  unsigned pc[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
     const int i = 16 * s + j;
     const float v = i < I ? wt[((size_t)i * K + k) * O + o] : 0.0f;
-    unsigned p1, p2, p3;
-    split3(v, p1, p2, p3);
-    P[e] = (unsigned short)(p1 >> 16);
-    P[per_plane + e] = (unsigned short)(p2 >> 16);
-    P[2 * per_plane + e] = (unsigned short)(p3 >> 16);
+    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    P[(p * per_plane + id) * 2] = pack8(&pc[p][0]);
+    P[(p * per_plane + id) * 2 + 1] = pack8(&pc[p][8]);
   }
 }
 
@@ -308,25 +319,28 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
 // 16-out step in flight under the 6*K*RM MFMAs of the current one.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pp_bf3_pack_wo_kernel(const float* __restrict__ wt,
-                                                             unsigned short* __restrict__ Q, int I,
-                                                             int K, int O, int nso, int Ipad) {
-  const long per_plane = (long)nso * K * Ipad * 16;
-  long e = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stepg = (long)gridDim.x * 256;
-  for (; e < per_plane; e += stepg) {
-    const int j = (int)(e & 15);
-    long q = e >> 4;
-    const int i = (int)(q % Ipad);
-    q /= Ipad;
-    const int k = (int)(q % K);
-    const int t = (int)(q / K);
+                                                             u32x4* __restrict__ Q, int I, int K,
+                                                             int O, int nso, int Ipad) {
+  // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
+  // 64-byte pieces of one weight row
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)Ipad * K * nso) return;
+  const int t = (int)(id % nso);
+  const int k = (int)((id / nso) % K);
+  const int i = (int)(id / ((long)nso * K));
+  unsigned pc[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
     const int o = 16 * t + j;
     const float v = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] : 0.0f;
-    unsigned p1, p2, p3;
-    split3(v, p1, p2, p3);
-    Q[e] = (unsigned short)(p1 >> 16);
-    Q[per_plane + e] = (unsigned short)(p2 >> 16);
-    Q[2 * per_plane + e] = (unsigned short)(p3 >> 16);
+    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+  }
+  const long per_plane = (long)nso * K * Ipad;  // slots of 32 bytes
+  const long slot = ((long)t * K + k) * Ipad + i;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    Q[(p * per_plane + slot) * 2] = pack8(&pc[p][0]);
+    Q[(p * per_plane + slot) * 2 + 1] = pack8(&pc[p][8]);
   }
 }
 
@@ -789,10 +803,9 @@ hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t*
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
-  const long per_plane = (long)sh.K * nstep * sh.O * 16;
-  const int pblocks = (int)std::min<long>((per_plane + 255) / 256, 4096);
-  hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3(pblocks), dim3(256), 0, st, wt,
-                     static_cast<unsigned short*>(ws), sh.I, sh.K, sh.O, nstep);
+  const long pslots = (long)sh.K * nstep * sh.O;
+  hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0, st,
+                     wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nstep);
   // variant: 64-row tiles once they fill the chip; two wave groups (split-k in the
   // block) when their basis buffers fit LDS.  PP_BF3_VARIANT=<rm><g> overrides (tuning).
   int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
@@ -862,10 +875,9 @@ hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt,
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
   const int nso = nso_of(sh), Ipad = ipad_of(sh);
-  const long per_plane = (long)nso * sh.K * Ipad * 16;
-  const int pblocks = (int)std::min<long>((per_plane + 255) / 256, 4096);
-  hipLaunchKernelGGL(pp_bf3_pack_wo_kernel, dim3(pblocks), dim3(256), 0, st, wt,
-                     static_cast<unsigned short*>(ws), sh.I, sh.K, sh.O, nso, Ipad);
+  const long pslots = (long)nso * sh.K * Ipad;
+  hipLaunchKernelGGL(pp_bf3_pack_wo_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0,
+                     st, wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nso, Ipad);
   // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
   int rm = sh.B >= 4096 && sh.K <= 6 ? 2 : 1;
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
