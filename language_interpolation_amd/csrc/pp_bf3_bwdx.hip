@@ -1,0 +1,340 @@
+// bf16x3 backward-input (scheme: pp_bf3_fwd.hip, header comment).
+#include "pp_bf3_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// backward-input on the same bf16x3 scheme:
+//   T[b,(k,i)] = sum_o gy[b,o] * w_t[i,k,o]      (bf16 MFMA, both operands split 3-way)
+//   gx[b,i]    = chain * sum_k dPhi[b,i,k] * T[b,(k,i)]          (fp32, in the epilogue)
+// Block = 4 waves = 4 adjacent 32-input tiles of one tile of 32*RM rows; a wave keeps
+// the K accumulators of its (rows x inputs) tile, so dPhi is evaluated once per pair.
+// gy is split on the fly, one chunk of 128 outs at a time, into LDS ([plane][step]
+// [half][row] x 16 B, double-buffered) and shared by the four waves; the weights come
+// pre-split from Q[plane][ostep][k][Ipad][16 outs], all K fragments of the next
+// 16-out step in flight under the 6*K*RM MFMAs of the current one.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pp_bf3_pack_wo_kernel(const float* __restrict__ wt,
+                                                             u32x4* __restrict__ Q, int I, int K,
+                                                             int O, int nso, int Ipad) {
+  // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
+  // 64-byte pieces of one weight row
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)Ipad * K * nso) return;
+  const int t = (int)(id % nso);
+  const int k = (int)((id / nso) % K);
+  const int i = (int)(id / ((long)nso * K));
+  unsigned pc[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int o = 16 * t + j;
+    const float v = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] : 0.0f;
+    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+  }
+  const long per_plane = (long)nso * K * Ipad;  // slots of 32 bytes
+  const long slot = ((long)t * K + k) * Ipad + i;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    Q[(p * per_plane + slot) * 2] = pack8(&pc[p][0]);
+    Q[(p * per_plane + slot) * 2 + 1] = pack8(&pc[p][8]);
+  }
+}
+
+constexpr int kOC = 8;  // 16-out steps per gy chunk
+
+#ifdef PP_TIMING
+__device__ unsigned long long pp_dbg_times[8 * 8192];
+#define PP_TICK(slot)                                                                   \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192)                         \
+    pp_dbg_times[blockIdx.x * 8 + (slot)] = wall_clock64();
+#else
+#define PP_TICK(slot)
+#endif
+
+template <int N, int K, int RM, int VW>
+__device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
+                                               const float* __restrict__ gy,
+                                               const void* __restrict__ Q, float* __restrict__ gx,
+                                               const PPShape& sh, const BasisTab& tab,
+                                               const DenseCoord3& dc, int nso, int Ipad,
+                                               u32x4* gyL) {
+  PP_TICK(0)
+  constexpr int ROWS = 32 * RM;
+  constexpr int kBufU = 3 * kOC * 2 * ROWS;
+  constexpr int FR = ROWS * 2 * kOC / 256;  // gy fragments (8 outs of one row) per thread per chunk
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r = lane & 31, h = lane >> 5;
+  const int b0 = blockIdx.x * ROWS;
+  const int i0 = (blockIdx.y * 4 + wv) * 32;  // < Ipad by construction of the grid
+  const int nchunk = (nso + kOC - 1) / kOC;
+
+  // producer: fragment f = tid + 256 m -> row f % ROWS, out group f / ROWS (8 outs)
+  const rsrc_t rg = make_rsrc3(gy, (unsigned)sh.B * sh.O * 4u);
+  int prow, pog[FR], pvoff[FR];
+  prow = threadIdx.x % ROWS;
+#pragma unroll
+  for (int m = 0; m < FR; ++m) {
+    pog[m] = (threadIdx.x + 256 * m) / ROWS;
+    pvoff[m] = (min(b0 + prow, sh.B - 1) * sh.O + pog[m] * 8) * 4;
+  }
+  float stage[FR][8];
+  auto gy_load = [&](int c) {
+#pragma unroll
+    for (int m = 0; m < FR; ++m) {
+      if constexpr (VW == 4) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rg, pvoff[m] + 4 * e, c * (kOC * 64), 0);
+          stage[m][e] = __uint_as_float(t.x); stage[m][e + 1] = __uint_as_float(t.y);
+          stage[m][e + 2] = __uint_as_float(t.z); stage[m][e + 3] = __uint_as_float(t.w);
+        }
+      } else if constexpr (VW == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rg, pvoff[m] + 4 * e, c * (kOC * 64), 0);
+          stage[m][e] = __uint_as_float(t.x); stage[m][e + 1] = __uint_as_float(t.y);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          stage[m][e] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(rg, pvoff[m] + 4 * e, c * (kOC * 64), 0));
+      }
+    }
+  };
+  auto gy_publish = [&](int c, int buf) {
+#pragma unroll
+    for (int m = 0; m < FR; ++m) {
+      const int obase = c * (kOC * 16) + pog[m] * 8;
+      unsigned pc[3][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = obase + e < sh.O ? stage[m][e] : 0.0f;  // outs past O belong to the next row
+        split3(v, pc[0][e], pc[1][e], pc[2][e]);
+      }
+      const int t = pog[m] >> 1, hh = pog[m] & 1;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        u32x4 w;
+        w.x = (pc[p][0] >> 16) | pc[p][1];
+        w.y = (pc[p][2] >> 16) | pc[p][3];
+        w.z = (pc[p][4] >> 16) | pc[p][5];
+        w.w = (pc[p][6] >> 16) | pc[p][7];
+        gyL[buf * kBufU + ((p * kOC + t) * 2 + hh) * ROWS + prow] = w;
+      }
+    }
+  };
+
+  // consumer
+  const rsrc_t rq = make_rsrc3(Q, (unsigned)(3u * nso * K * Ipad * 32u));
+  const int vq_off = ((i0 + r) * 2 + h) * 16;
+  const int k_bytes = Ipad * 32;          // one (plane, ostep, k) slab
+  const int t_bytes = K * k_bytes;        // one (plane, ostep)
+  const int plane_bytes = nso * t_bytes;
+  auto wload = [&](int t, bf16x8 (&w)[K][3]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        w[k][p] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rq, vq_off, p * plane_bytes + t * t_bytes + k * k_bytes, 0));
+  };
+  auto aload = [&](int buf, int tt, bf16x8 (&a)[RM][3]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[rm][p] = __builtin_bit_cast(
+            bf16x8, gyL[buf * kBufU + ((p * kOC + tt) * 2 + h) * ROWS + rm * 32 + r]);
+  };
+
+  f32x16 acc[K][RM];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[k][rm][q] = 0.0f;
+  auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[K][3]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+          acc[k][rm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm][PA[c]], w[k][PB[c]],
+                                                               acc[k][rm], 0, 0, 0);
+  };
+
+  // x of this lane's (row, input) pairs for the epilogue: issued at the start of the
+  // LAST chunk (when the gy staging registers are idle), consumed after the loop
+  const int i = i0 + r;
+  const rsrc_t rx = make_rsrc3(x, (unsigned)sh.B * sh.I * 4u);
+  const int icol = min(i, sh.I - 1);
+  float xv[RM][16];
+  auto x_load = [&]() {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = min(b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, sh.B - 1);
+        xv[rm][q] = __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(rx, (row * sh.I + icol) * 4, 0, 0));
+      }
+  };
+  bf16x8 W[2][K][3], A[2][RM][3];
+  gy_load(0);
+  wload(0, W[0]);
+  PP_TICK(1)
+  gy_publish(0, 0);
+  __syncthreads();
+  PP_TICK(2)
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunk;  // block-uniform
+    if (more) gy_load(c + 1);
+    else x_load();
+    const int nt = min(kOC, nso - c * kOC);  // even: nso is
+    aload(buf, 0, A[0]);
+    for (int tt = 0; tt < nt; tt += 2) {
+      const int t = c * kOC + tt;
+      // sched_barrier: keep the next step's loads ahead of this step's MFMAs (the
+      // scheduler otherwise sinks them to their first use to save registers)
+      wload(t + 1, W[1]);
+      aload(buf, tt + 1, A[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(A[0], W[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      wload(t + 2, W[0]);
+      aload(buf, min(tt + 2, kOC - 1), A[0]);  // (past the chunk: a harmless re-read)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(A[1], W[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PP_TICK(3 + 2 * (c & 1))
+    if (more) gy_publish(c + 1, buf ^ 1);
+    __syncthreads();
+    PP_TICK(4 + 2 * (c & 1))
+  }
+
+  // epilogue: lane owns input column i0 + r for 16*RM rows
+  if (i < sh.I) {
+    const float chain = (sh.length * dc.inv_w) * sh.out_scale;  // dxi/dx = L/(2/S)
+    constexpr int S = Geom3<N, K>::S, stride = Geom3<N, K>::stride;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float xq = xv[rm][q];
+        const float t = ((xq + sh.half) * dc.inv_len) * sh.Sf;
+        const float tc = __builtin_amdgcn_fmed3f(t, -1.0f, sh.Sf);
+        int si = (int)tc;
+        si = min(max(si, 0), sh.S - 1);
+        const int s = (__builtin_fabsf(t) < 9.2e18f) ? si : 0;
+        const float x_min = (float)s * dc.w2 - 1.0f;
+        const float xi = sh.length * ((xq - x_min) * dc.inv_w) - sh.half;
+        float l[N], dl[N];
+        pp_lagrange_d<N>(xi, tab, l, dl);
+        float gsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          float d = 0.0f;
+#pragma unroll
+          for (int sq = 0; sq < S; ++sq) {
+            const int j = k - sq * stride;
+            if (j >= 0 && j < N) d = (s == sq) ? dl[j] : d;
+          }
+          gsum = fmaf(d, acc[k][rm][q], gsum);
+        }
+        if (row < sh.B) gx[(size_t)row * sh.I + i] = gsum * chain;
+      }
+  }
+  PP_TICK(7)
+}
+
+template <int N, int K, int RM>
+__global__ __launch_bounds__(256) void pp_bwd_x_bf3_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ gy,
+                                                           const void* __restrict__ Q,
+                                                           float* __restrict__ gx, PPShape sh,
+                                                           BasisTab tab, DenseCoord3 dc, int nso,
+                                                           int Ipad, int vw) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 gyL[];  // [2][3][kOC][2][32*RM] x 16 B
+  // vw: widest aligned vector load of a gy row (block-uniform), fixed per body so the
+  // staging loads stay straight-line code
+  if (vw == 4) bwd_x_bf3_body<N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  else if (vw == 2) bwd_x_bf3_body<N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  else bwd_x_bf3_body<N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+}
+
+}  // namespace
+
+// ---- backward-input ----
+namespace {
+int nso_of(const PPShape& sh) { return ((sh.O + 31) / 32) * 2; }   // 16-out steps, even
+int ipad_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 32; }
+
+template <int N, int K, int RM>
+hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, float* gx,
+                            const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
+                            hipStream_t st) {
+  const size_t lds = (size_t)2 * 3 * kOC * 2 * 32 * RM * 16;
+  if (lds > 48 * 1024) {
+    static bool once = false;  // per instantiation
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<N, K, RM>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      once = true;
+    }
+  }
+  const int vw = sh.O % 4 == 0 ? 4 : (sh.O % 2 == 0 ? 2 : 1);
+  dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (ipad_of(sh) + 127) / 128);
+  hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<N, K, RM>), grid, dim3(256), lds, st, x, gy, ws, gx, sh,
+                     tab, dc, nso_of(sh), ipad_of(sh), vw);
+  return hipGetLastError();
+}
+}  // namespace
+
+bool pp_bf3_bwd_x_supported(const PPShape& sh) {
+  if (!pp_dense_supported(sh)) return false;
+  return (long)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32 < (1L << 31);
+}
+
+size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh) {
+  return (size_t)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32;
+}
+
+hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
+                               void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  DenseCoord3 dc;
+  dc.w2 = 2.0f / (float)sh.S;
+  dc.inv_w = (float)sh.S / 2.0f;
+  dc.inv_len = 1.0f / sh.length;
+  const int nso = nso_of(sh), Ipad = ipad_of(sh);
+  const long pslots = (long)nso * sh.K * Ipad;
+  hipLaunchKernelGGL(pp_bf3_pack_wo_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0,
+                     st, wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nso, Ipad);
+  // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
+  int rm = sh.B >= 4096 && sh.K <= 6 ? 2 : 1;
+  if (const char* v = getenv("PP_BF3_BWDX_RM")) {
+    const int c = atoi(v);
+    if ((c == 1 || c == 2) && (c == 1 || sh.K <= 6)) rm = c;
+  }
+#define X(N_, K_)                                                                          \
+  if (sh.n == N_ && sh.K == K_) {                                                          \
+    if constexpr (K_ <= 6) {                                                               \
+      if (rm == 2) return launch_bwd_x_bf3<N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, st);     \
+    }                                                                                      \
+    return launch_bwd_x_bf3<N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, st);                    \
+  }
+  PP_BF3_COMBOS(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+

@@ -1,0 +1,318 @@
+// Dense path on the bf16 matrix cores with a 3-way operand split ("bf16x3").
+//
+// The f32-input MFMA runs at the fp32 vector rate (157 TFLOP/s); the bf16 MFMA
+// (v_mfma_f32_32x32x16_bf16) is 16x faster per k-value.  An fp32 value splits
+// EXACTLY into three bf16 pieces (a = a1 + a2 + a3, 8 significant bits each, by
+// truncation and exact residuals), every bf16 x bf16 product is exact in the
+// MFMA's fp32 accumulator, and the six leading cross terms
+//     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1
+// reproduce the fp32 product to ~2^-23 relative (dropped: a2b3, a3b2, a3b3).  Six
+// bf16 MFMAs per k-step cost 6/16 of one f32 MFMA step: 2.7x the fp32 matrix rate
+// at fp32-level accuracy (the parity bar is 1e-5 relative; measured error ~1e-7).
+//
+// forward  y[b,o] = sum_{i,k} Phi[b,i,k] * w_t[i,k,o]
+//   k-dimension ordered (k, i): one MFMA k-step = 16 consecutive inputs at a fixed
+//   weight index k, so a lane evaluates the basis of an input once and uses its K
+//   columns in K different k-steps.  Block = 4 waves = 4 column tiles (64 outs each)
+//   of one 32-row tile; per step of 16 inputs every wave evaluates and splits the
+//   basis of 2 inputs per lane and publishes it in LDS ([plane][k][half][row] x 16 B,
+//   conflict-free ds_read_b128); weights come pre-split from a packed buffer
+//   P[plane][k][step][out][16 inputs] (coalesced 16-byte loads), written once per
+//   call by pp_bf3_pack_w_kernel.
+#include "pp_bf3_common.h"
+
+namespace {
+
+// P[plane][k][step][out][16]: bf16 pieces of w_t[i = 16*step + j][k][out].  One thread
+// per (k, step, out): 16 reads coalesced over `out`, two 16-byte stores per plane.
+__global__ __launch_bounds__(256) void pp_bf3_pack_w_kernel(const float* __restrict__ wt,
+                                                            u32x4* __restrict__ P, int I, int K,
+                                                            int O, int nstep) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_plane = (long)K * nstep * O;  // in (k, step, out) slots of 32 bytes
+  if (id >= per_plane) return;
+  const int o = (int)(id % O);
+  const int s = (int)((id / O) % nstep);
+  const int k = (int)(id / ((long)O * nstep));
+  unsigned pc[3][16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = 16 * s + j;
+    const float v = i < I ? wt[((size_t)i * K + k) * O + o] : 0.0f;
+    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    P[(p * per_plane + id) * 2] = pack8(&pc[p][0]);
+    P[(p * per_plane + id) * 2 + 1] = pack8(&pc[p][8]);
+  }
+}
+
+template <int N, int K, int RM, int NT, int G>
+__global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __restrict__ x,
+                                                             const void* __restrict__ P,
+                                                             float* __restrict__ y, PPShape sh,
+                                                             BasisTab tab, DenseCoord3 dc,
+                                                             int nstep) {
+  // block = G groups of 4 waves.  A group = 4 column tiles (32*NT outs each) x one tile
+  // of 32*RM rows; every W fragment a wave loads feeds RM row tiles.  With G = 2 the two
+  // groups take alternate 16-input steps of the SAME output tile (split-k inside the
+  // block, two waves per SIMD: one group's waits and basis evaluation sit under the
+  // other's MFMAs) and add their accumulators through LDS at the end.  nstep is a
+  // multiple of G (the packed weights are zero-padded to it).
+  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [G][2][3][K][2][32*RM] x 16 B
+  constexpr int ROWS = 32 * RM;
+  constexpr int kBufU = 3 * K * 2 * ROWS;
+  const int lane = threadIdx.x & 63;
+  // wave-uniform ids in SGPRs (a VGPR step offset would turn every buffer load into a
+  // readfirstlane loop)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cw = wv & 3;
+  const int g = G > 1 ? wv >> 2 : 0;
+  const int r = lane & 31, h = lane >> 5;
+  const int b0 = blockIdx.x * ROWS;
+  const int o0 = (blockIdx.y * 4 + cw) * (32 * NT);
+  // producer role: inputs 16*s + 8*hb + ipos, +1 of rows b0 + r + 32*rm
+  const int hb = cw >> 1, ipos = 4 * (cw & 1) + 2 * h;
+  const rsrc_t rx = make_rsrc3(x, (unsigned)sh.B * sh.I * 4u);
+  int vx_off[RM];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+    vx_off[rm] = (min(b0 + rm * 32 + r, sh.B - 1) * sh.I + 8 * hb + ipos) * 4;
+  u32x4* phiG = phiL + g * 2 * kBufU;
+  unsigned* phiW = reinterpret_cast<unsigned*>(phiG);
+  // consumer role
+  const rsrc_t rp = make_rsrc3(P, (unsigned)(3u * K * nstep * sh.O * 32u));
+  int vcol[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) vcol[nt] = (min(o0 + nt * 32 + r, sh.O - 1) * 2 + h) * 16;
+  const int step_bytes = sh.O * 32;        // one (plane, k, step) slab
+  const int k_bytes = nstep * step_bytes;  // one (plane, k)
+  const int plane_bytes = K * k_bytes;
+
+  f32x16 acc[RM][NT];
+#pragma unroll
+  for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[rm][nt][q] = 0.0f;
+
+  // s: global step index (16 inputs); t: this group's iteration, s = t*G + g
+  auto xload = [&](int s, float (&xv)[RM][2]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      xv[rm][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx_off[rm], 64 * s, 0));
+      xv[rm][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx_off[rm] + 4, 64 * s, 0));
+    }
+  };
+  auto produce = [&](int s, int buf, const float (&xv)[RM][2]) {
+    const int i0 = 16 * s + 8 * hb + ipos;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      float pa[K], pb[K];
+      phi3<N, K>(xv[rm][0], i0 < sh.I, sh, tab, dc, pa);
+      phi3<N, K>(xv[rm][1], i0 + 1 < sh.I, sh, tab, dc, pb);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        unsigned a1, a2, a3, c1, c2, c3;
+        split3(pa[k], a1, a2, a3);
+        split3(pb[k], c1, c2, c3);
+        const int base = (buf * kBufU + (k * 2 + hb) * ROWS + rm * 32 + r) * 4 + (ipos >> 1);
+        phiW[base] = (a1 >> 16) | c1;
+        phiW[base + K * 2 * ROWS * 4] = (a2 >> 16) | c2;
+        phiW[base + 2 * K * 2 * ROWS * 4] = (a3 >> 16) | c3;
+      }
+    }
+  };
+  auto wload = [&](int s, int k, bf16x8 (&w)[3][NT]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        w[p][nt] = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rp, vcol[nt], p * plane_bytes + k * k_bytes + s * step_bytes, 0));
+  };
+  auto aload = [&](int buf, int k, bf16x8 (&a)[RM][3]) {
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[rm][p] = __builtin_bit_cast(
+            bf16x8, phiG[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
+  };
+  auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[3][NT]) {
+    // the six leading cross terms, small ones first, a1*b1 last
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[rm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm][PA[c]], w[PB[c]][nt],
+                                                                acc[rm][nt], 0, 0, 0);
+  };
+
+  const int T = nstep / G;
+  float xv[RM][2], xn[RM][2];
+  xload(g, xv);
+  produce(g, 0, xv);
+  xload(G + g, xv);
+  // two fragment sets in ping-pong over the flattened (step, k) sequence: the W loads
+  // of k-step q+1 are in flight, and its A fragments are read, under the MFMAs of q
+  bf16x8 W[2][3][NT], A[2][RM][3];
+  wload(g, 0, W[0]);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  auto stepfn = [&](int t, auto par) {
+    constexpr int P0 = decltype(par)::value;
+    const int buf = t & 1;
+    const int s = t * G + g;
+    xload(s + 2 * G, xn);
+    aload(buf, 0, A[P0 & 1]);
+    if (t + 1 < T) produce(s + G, buf ^ 1, xv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int cur = (k + P0) & 1, nxt = cur ^ 1;
+      if (k + 1 < K) {
+        wload(s, k + 1, W[nxt]);
+        aload(buf, k + 1, A[nxt]);
+      } else {
+        wload(s + G, 0, W[nxt]);
+      }
+      mm(A[cur], W[cur]);
+    }
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) {
+      xv[rm][0] = xn[rm][0];
+      xv[rm][1] = xn[rm][1];
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < T; t += 2) {
+    stepfn(t, std::integral_constant<int, 0>{});
+    if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{});
+  }
+
+  // accumulator tiles of this wave: tix = rm*NT + nt
+  constexpr int NTILE = RM * NT;
+  auto store_tile = [&](auto tc, const float* part) {
+    constexpr int tix = decltype(tc)::value;
+    constexpr int rm = tix / NT, nt = tix % NT;
+    const int col = o0 + nt * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      float v = acc[rm][nt][q];
+      if (part) v += part[q * 64];
+      if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = v * sh.out_scale;
+    }
+  };
+  if constexpr (G == 1) {
+    static_for<NTILE>([&](auto tc) { store_tile(tc, nullptr); });
+  } else {
+    // group g finishes the tiles with tix % 2 == g (all of them in group 0 when there
+    // is only one) and hands the others to the partner wave (same cw, other group)
+    // through LDS (the basis buffers are free: the loop ended on a barrier)
+    constexpr int NX = NTILE > 1 ? NTILE / 2 : 1;  // tiles a wave hands over
+    float* red = reinterpret_cast<float*>(phiL);   // [g][cw][NX][16][64]
+    float* mine = red + ((g * 4 + cw) * NX * 16) * 64 + lane;
+    const float* theirs = red + (((g ^ 1) * 4 + cw) * NX * 16) * 64 + lane;
+    auto exchange = [&](auto gc) {
+      constexpr int GS = decltype(gc)::value;  // this wave's group
+      static_for<NTILE>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        constexpr bool keep = NTILE == 1 ? GS == 0 : (T & 1) == GS;
+        if constexpr (!keep) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) mine[((T >> 1) * 16 + q) * 64] = acc[T / NT][T % NT][q];
+        }
+      });
+      __syncthreads();
+      static_for<NTILE>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        constexpr bool keep = NTILE == 1 ? GS == 0 : (T & 1) == GS;
+        if constexpr (keep) store_tile(tc, theirs + (T >> 1) * 16 * 64);
+      });
+    };
+    if (g == 0) exchange(std::integral_constant<int, 0>{});
+    else exchange(std::integral_constant<int, 1>{});
+  }
+}
+
+// 16-input steps, padded to even so the two-group kernel splits them evenly
+int nstep_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 2; }
+
+template <int N, int K, int RM, int NT, int G>
+hipError_t launch_bf3(const float* x, const void* ws, float* y, const PPShape& sh,
+                      const BasisTab& tab, const DenseCoord3& dc, int nstep, hipStream_t st) {
+  size_t lds = (size_t)G * 2 * 3 * K * 2 * 32 * RM * 16;
+  if (G == 2) lds = std::max(lds, (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    static bool once = false;  // per instantiation
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<N, K, RM, NT, G>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      once = true;
+    }
+  }
+  dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 128 * NT - 1) / (128 * NT));
+  hipLaunchKernelGGL((pp_fwd_bf3_kernel<N, K, RM, NT, G>), grid, dim3(256 * G), lds, st, x, ws, y, sh,
+                     tab, dc, nstep);
+  return hipGetLastError();
+}
+
+}  // namespace
+bool pp_bf3_supported(const PPShape& sh) {
+  if (!pp_dense_supported(sh)) return false;
+  return (long)3 * sh.K * nstep_of(sh) * sh.O * 32 < (1L << 31);
+}
+
+size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
+  return (size_t)3 * sh.K * nstep_of(sh) * sh.O * 32;
+}
+
+hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                             const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  const int nstep = nstep_of(sh);
+  DenseCoord3 dc;
+  dc.w2 = 2.0f / (float)sh.S;
+  dc.inv_w = (float)sh.S / 2.0f;
+  dc.inv_len = 1.0f / sh.length;
+  const long pslots = (long)sh.K * nstep * sh.O;
+  hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0, st,
+                     wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nstep);
+  // variant: 64-row tiles once they fill the chip (K <= 6: two groups' basis buffers fit
+  // LDS); waves of 32 outs when O <= 128 so all four column waves have work.
+  // PP_BF3_VARIANT=<rm><nt> overrides (tuning).
+  int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
+  int nt = sh.O > 128 ? 2 : 1;
+  if (const char* v = getenv("PP_BF3_VARIANT")) {
+    const int code = atoi(v);
+    if (code / 10 >= 1 && code / 10 <= 2 && code % 10 >= 1 && code % 10 <= 2) {
+      rm = sh.K <= 6 ? code / 10 : 1;
+      nt = code % 10;
+    }
+  }
+#define X(N_, K_)                                                                            \
+  if (sh.n == N_ && sh.K == K_) {                                                            \
+    hipError_t e = hipErrorInvalidValue;                                                     \
+    if constexpr (K_ <= 6) {                                                                 \
+      if (rm == 2 && nt == 2) e = launch_bf3<N_, K_, 2, 2, 2>(x, ws, y, sh, tab, dc, nstep, st); \
+      else if (rm == 2) e = launch_bf3<N_, K_, 2, 1, 2>(x, ws, y, sh, tab, dc, nstep, st);   \
+    }                                                                                        \
+    if (rm == 1 && nt == 2) e = launch_bf3<N_, K_, 1, 2, 2>(x, ws, y, sh, tab, dc, nstep, st); \
+    else if (rm == 1) e = launch_bf3<N_, K_, 1, 1, 2>(x, ws, y, sh, tab, dc, nstep, st);     \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                   \
+    return e;                                                                                \
+  }
+  PP_BF3_COMBOS(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+

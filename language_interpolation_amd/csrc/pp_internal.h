@@ -55,7 +55,7 @@ hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float e
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
 
-// ---- dense path on bf16 MFMA with a 3-way fp32 split (pp_bf3.hip) ----
+// ---- dense path on bf16 MFMA with a 3-way fp32 split (pp_bf3_fwd.hip, pp_bf3_bwdx.hip, pp_bf3_bwdw.hip; shared: pp_bf3_common.h) ----
 bool pp_bf3_supported(const PPShape& sh);
 size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,

@@ -1,7 +1,7 @@
 // Developer tool: phase timestamps of pp_bwd_x_bf3_kernel (built with -DPP_TIMING from
 // the kernel source itself).  Prints per-phase durations for a few blocks.
 #define PP_TIMING 1
-#include "../language_interpolation_amd/csrc/pp_bf3.hip"
+#include "../language_interpolation_amd/csrc/pp_bf3_bwdx.hip"
 #include <cstdio>
 #include <vector>
 #include <cmath>
