@@ -67,6 +67,9 @@ enum {
   PP_FWD_DENSE = 2,   /* expanded-basis x weight on f32 MFMA (small K only) */
   PP_FWD_BF16X3 = 3,  /* same contraction on bf16 MFMA, operands split 3-way (fp32-level accuracy);
                          needs a workspace: pp_forward_ws_f32 */
+  PP_FWD_FP16X2 = 4,  /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor into fp16's
+                         range, fp32 fix-up of tiles whose basis does not fit (fp32-level accuracy);
+                         needs a workspace */
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */

@@ -103,7 +103,7 @@ int pp_segment_ids_f32(const float* x, int32_t* seg, int B, int I, int S, float 
 
 static int fwd_auto(const PPShape& sh, bool have_ws) {
   if (!dense_preferred(sh)) return PP_FWD_GATHER;
-  if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_BF16X3;
+  if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_FP16X2;
   return PP_FWD_DENSE;
 }
 
@@ -111,7 +111,8 @@ size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discont
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
   if (method == PP_METHOD_AUTO) method = fwd_auto(sh, true);
-  if (method == PP_FWD_BF16X3 && pp_bf3_supported(sh)) return pp_bf3_fwd_workspace_bytes(sh);
+  if ((method == PP_FWD_BF16X3 || method == PP_FWD_FP16X2) && pp_bf3_supported(sh))
+    return pp_bf3_fwd_workspace_bytes(sh);
   return 0;
 }
 
@@ -129,7 +130,7 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
   make_basis(tab, n, length, nodes);
   if (method == PP_METHOD_AUTO) {
     method = fwd_auto(sh, workspace != nullptr);
-    if (method == PP_FWD_BF16X3 && workspace_bytes < pp_bf3_fwd_workspace_bytes(sh))
+    if (method == PP_FWD_FP16X2 && workspace_bytes < pp_bf3_fwd_workspace_bytes(sh))
       method = PP_FWD_DENSE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -138,9 +139,11 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
     if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_fwd_dense(x, w_t, y, seg_out, sh, tab, st));
   }
-  if (method == PP_FWD_BF16X3) {
+  if (method == PP_FWD_BF16X3 || method == PP_FWD_FP16X2) {
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_fwd_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
+    if (method == PP_FWD_FP16X2)
+      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, st));
     return hip_rc(pp_launch_fwd_bf3(x, w_t, y, seg_out, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;

@@ -42,14 +42,6 @@ __global__ __launch_bounds__(256) void pp_bf3_pack_wo_kernel(const float* __rest
 
 constexpr int kOC = 8;  // 16-out steps per gy chunk
 
-#ifdef PP_TIMING
-__device__ unsigned long long pp_dbg_times[8 * 8192];
-#define PP_TICK(slot)                                                                   \
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192)                         \
-    pp_dbg_times[blockIdx.x * 8 + (slot)] = wall_clock64();
-#else
-#define PP_TICK(slot)
-#endif
 
 template <int N, int K, int RM, int VW>
 __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,

@@ -10,6 +10,12 @@
 // bf16 MFMAs per k-step cost 6/16 of one f32 MFMA step: 2.7x the fp32 matrix rate
 // at fp32-level accuracy (the parity bar is 1e-5 relative; measured error ~1e-7).
 //
+// The same kernels also run the "fp16x2" scheme (SchemeH2 in pp_bf3_common.h: two fp16
+// pieces, three MFMAs per k-step instead of six): the weights are scaled per tensor by a
+// power of two into fp16's range (pp_absmax_kernel + the pack kernel), the basis is used
+// as is, and a tile that meets a basis value too large for fp16 pieces (far extrapolation)
+// is recomputed in plain fp32 by its block.
+//
 // forward  y[b,o] = sum_{i,k} Phi[b,i,k] * w_t[i,k,o]
 //   k-dimension ordered (k, i): one MFMA k-step = 16 consecutive inputs at a fixed
 //   weight index k, so a lane evaluates the basis of an input once and uses its K
@@ -23,34 +29,64 @@
 
 namespace {
 
-// P[plane][k][step][out][16]: bf16 pieces of w_t[i = 16*step + j][k][out].  One thread
-// per (k, step, out): 16 reads coalesced over `out`, two 16-byte stores per plane.
-__global__ __launch_bounds__(256) void pp_bf3_pack_w_kernel(const float* __restrict__ wt,
-                                                            u32x4* __restrict__ P, int I, int K,
-                                                            int O, int nstep) {
+// P[plane][k][step][out][16]: 16-bit pieces of w_t[i = 16*step + j][k][out] (times the
+// tensor's power-of-two scale for a ranged scheme).  One thread per (k, step, out): 16
+// reads coalesced over `out`, two 16-byte stores per plane.  ws = header | P.
+template <class SC>
+__global__ __launch_bounds__(256) void pp_split_pack_w_kernel(const float* __restrict__ wt,
+                                                              void* __restrict__ ws, int I, int K,
+                                                              int O, int nstep) {
   const long id = (long)blockIdx.x * 256 + threadIdx.x;
   const long per_plane = (long)K * nstep * O;  // in (k, step, out) slots of 32 bytes
   if (id >= per_plane) return;
+  float scale = 1.0f, inv;
+  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
+  u32x4* P = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + kWsHeader);
   const int o = (int)(id % O);
   const int s = (int)((id / O) % nstep);
   const int k = (int)(id / ((long)O * nstep));
-  unsigned pc[3][16];
+  float v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int i = 16 * s + j;
-    const float v = i < I ? wt[((size_t)i * K + k) * O + o] : 0.0f;
-    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+    v[j] = i < I ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
   }
+  u32x4 lo[SC::PL], hi[SC::PL];
+  split16<SC>(v, lo, hi);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    P[(p * per_plane + id) * 2] = pack8(&pc[p][0]);
-    P[(p * per_plane + id) * 2 + 1] = pack8(&pc[p][8]);
+  for (int p = 0; p < SC::PL; ++p) {
+    P[(p * per_plane + id) * 2] = lo[p];
+    P[(p * per_plane + id) * 2 + 1] = hi[p];
   }
 }
 
-template <int N, int K, int RM, int NT, int G>
+// plain fp32 recomputation of a tile (rows b0..b0+rows, outs o_lo..o_hi) by the whole
+// block: the rare way out when a ranged scheme met a basis value it cannot represent
+template <int N, int K>
+__device__ __forceinline__ void fwd_tile_fp32(const float* __restrict__ x, const float* __restrict__ wt,
+                                           float* __restrict__ y, const PPShape& sh,
+                                           const BasisTab& tab, const DenseCoord3& dc, int b0,
+                                           int rows, int o_lo, int o_hi) {
+  const int ncol = o_hi - o_lo;
+  for (int idx = threadIdx.x; idx < rows * ncol; idx += blockDim.x) {
+    const int row = b0 + idx / ncol, col = o_lo + idx % ncol;
+    if (row >= sh.B) continue;
+    float sum = 0.0f;
+    for (int i = 0; i < sh.I; ++i) {
+      float phi[K];
+      phi3<N, K>(x[(size_t)row * sh.I + i], true, sh, tab, dc, phi);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (phi[k] != 0.0f) sum = fmaf(phi[k], wt[((size_t)i * K + k) * sh.O + col], sum);
+    }
+    y[(size_t)row * sh.O + col] = sum * sh.out_scale;
+  }
+}
+
+template <class SC, int N, int K, int RM, int NT, int G>
 __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __restrict__ x,
-                                                             const void* __restrict__ P,
+                                                             const float* __restrict__ wt,
+                                                             const void* __restrict__ ws,
                                                              float* __restrict__ y, PPShape sh,
                                                              BasisTab tab, DenseCoord3 dc,
                                                              int nstep) {
@@ -60,9 +96,12 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   // block, two waves per SIMD: one group's waits and basis evaluation sit under the
   // other's MFMAs) and add their accumulators through LDS at the end.  nstep is a
   // multiple of G (the packed weights are zero-padded to it).
-  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [G][2][3][K][2][32*RM] x 16 B
+  using frag = typename SC::frag;
+  constexpr int PL = SC::PL;
+  PP_TICK(0)
+  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [G][2][PL][K][2][32*RM] x 16 B
   constexpr int ROWS = 32 * RM;
-  constexpr int kBufU = 3 * K * 2 * ROWS;
+  constexpr int kBufU = PL * K * 2 * ROWS;
   const int lane = threadIdx.x & 63;
   // wave-uniform ids in SGPRs (a VGPR step offset would turn every buffer load into a
   // readfirstlane loop)
@@ -82,7 +121,8 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   u32x4* phiG = phiL + g * 2 * kBufU;
   unsigned* phiW = reinterpret_cast<unsigned*>(phiG);
   // consumer role
-  const rsrc_t rp = make_rsrc3(P, (unsigned)(3u * K * nstep * sh.O * 32u));
+  const rsrc_t rp = make_rsrc3(static_cast<const char*>(ws) + kWsHeader,
+                               (unsigned)((unsigned)PL * K * nstep * sh.O * 32u));
   int vcol[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) vcol[nt] = (min(o0 + nt * 32 + r, sh.O - 1) * 2 + h) * 16;
@@ -106,54 +146,50 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
       xv[rm][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx_off[rm] + 4, 64 * s, 0));
     }
   };
+  float lmax = 0.0f;  // ranged schemes: largest |basis value| this lane produced
   auto produce = [&](int s, int buf, const float (&xv)[RM][2]) {
     const int i0 = 16 * s + 8 * hb + ipos;
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
       float pa[K], pb[K];
-      phi3<N, K>(xv[rm][0], i0 < sh.I, sh, tab, dc, pa);
-      phi3<N, K>(xv[rm][1], i0 + 1 < sh.I, sh, tab, dc, pb);
+      phi3<N, K>(xv[rm][0], i0 < sh.I, sh, tab, dc, pa, SC::kRanged ? &lmax : nullptr);
+      phi3<N, K>(xv[rm][1], i0 + 1 < sh.I, sh, tab, dc, pb, SC::kRanged ? &lmax : nullptr);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        unsigned a1, a2, a3, c1, c2, c3;
-        split3(pa[k], a1, a2, a3);
-        split3(pb[k], c1, c2, c3);
+        unsigned w[PL];
+        SC::split_pair(pa[k], pb[k], w);
         const int base = (buf * kBufU + (k * 2 + hb) * ROWS + rm * 32 + r) * 4 + (ipos >> 1);
-        phiW[base] = (a1 >> 16) | c1;
-        phiW[base + K * 2 * ROWS * 4] = (a2 >> 16) | c2;
-        phiW[base + 2 * K * 2 * ROWS * 4] = (a3 >> 16) | c3;
+#pragma unroll
+        for (int p = 0; p < PL; ++p) phiW[base + p * K * 2 * ROWS * 4] = w[p];
       }
     }
   };
-  auto wload = [&](int s, int k, bf16x8 (&w)[3][NT]) {
+  auto wload = [&](int s, int k, frag (&w)[PL][NT]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PL; ++p)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         w[p][nt] = __builtin_bit_cast(
-            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        rp, vcol[nt], p * plane_bytes + k * k_bytes + s * step_bytes, 0));
+            frag, __builtin_amdgcn_raw_buffer_load_b128(
+                      rp, vcol[nt], p * plane_bytes + k * k_bytes + s * step_bytes, 0));
   };
-  auto aload = [&](int buf, int k, bf16x8 (&a)[RM][3]) {
+  auto aload = [&](int buf, int k, frag (&a)[RM][PL]) {
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PL; ++p)
         a[rm][p] = __builtin_bit_cast(
-            bf16x8, phiG[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
+            frag, phiG[buf * kBufU + ((p * K + k) * 2 + h) * ROWS + rm * 32 + r]);
   };
-  auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[3][NT]) {
-    // the six leading cross terms, small ones first, a1*b1 last
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto mm = [&](const frag (&a)[RM][PL], const frag (&w)[PL][NT]) {
+    // the scheme's cross terms, small ones first, a1*b1 last
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int c = 0; c < SC::NC; ++c)
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[rm][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm][PA[c]], w[PB[c]][nt],
-                                                                acc[rm][nt], 0, 0, 0);
+          acc[rm][nt] = SC::mfma(a[rm][SC::pa(c)], w[SC::pb(c)][nt], acc[rm][nt]);
   };
 
   const int T = nstep / G;
@@ -161,30 +197,55 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   xload(g, xv);
   produce(g, 0, xv);
   xload(G + g, xv);
-  // two fragment sets in ping-pong over the flattened (step, k) sequence: the W loads
-  // of k-step q+1 are in flight, and its A fragments are read, under the MFMAs of q
-  bf16x8 W[2][3][NT], A[2][RM][3];
-  wload(g, 0, W[0]);
+  // one W fragment set per weight index k: as soon as the MFMAs of (step, k) are issued,
+  // the set is refilled for (next step, k), so every weight load has K-1 k-steps of MFMAs
+  // to arrive under (one k-step is shorter than an L2 round trip).  A fragments (LDS):
+  // two sets in ping-pong, one k-step ahead.
+  // When K sets do not fit the register budget of two waves per SIMD: two sets in
+  // ping-pong over the flattened (step, k) sequence instead (one k-step ahead).
+  constexpr bool RING = K * PL * NT * 4 <= 96;
+  constexpr int NW = RING ? K : 2;
+  frag W[NW][PL][NT], A[2][RM][PL];
+  if constexpr (RING) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) wload(g, k, W[k]);
+  } else {
+    wload(g, 0, W[0]);
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-  auto stepfn = [&](int t, auto par) {
+  PP_TICK(1)
+  // LATE = false: evaluate the next step's basis, then run this step's MFMAs; LATE = true:
+  // the other way round.  The two groups of a block use opposite orders, so on every SIMD
+  // one wave issues vector work while the other issues matrix work.
+  auto stepfn = [&](int t, auto par, auto late) {
     constexpr int P0 = decltype(par)::value;
+    constexpr bool LATE = decltype(late)::value;
     const int buf = t & 1;
     const int s = t * G + g;
     xload(s + 2 * G, xn);
     aload(buf, 0, A[P0 & 1]);
-    if (t + 1 < T) produce(s + G, buf ^ 1, xv);
+    if (!LATE && t + 1 < T) produce(s + G, buf ^ 1, xv);
+    if (!LATE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int cur = (k + P0) & 1, nxt = cur ^ 1;
-      if (k + 1 < K) {
-        wload(s, k + 1, W[nxt]);
-        aload(buf, k + 1, A[nxt]);
+      if constexpr (RING) {
+        if (k + 1 < K) aload(buf, k + 1, A[nxt]);
+        mm(A[cur], W[k]);
+        wload(s + G, k, W[k]);
       } else {
-        wload(s + G, 0, W[nxt]);
+        if (k + 1 < K) {
+          wload(s, k + 1, W[nxt]);
+          aload(buf, k + 1, A[nxt]);
+        } else {
+          wload(s + G, 0, W[nxt]);
+        }
+        mm(A[cur], W[cur]);
       }
-      mm(A[cur], W[cur]);
     }
+    if (LATE) __builtin_amdgcn_sched_barrier(0);
+    if (LATE && t + 1 < T) produce(s + G, buf ^ 1, xv);
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
       xv[rm][0] = xn[rm][0];
@@ -192,11 +253,22 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
     }
     __syncthreads();
   };
-  for (int t = 0; t < T; t += 2) {
-    stepfn(t, std::integral_constant<int, 0>{});
-    if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{});
-  }
+  auto run = [&](auto late) {
+    for (int t = 0; t < T; t += 2) {
+      stepfn(t, std::integral_constant<int, 0>{}, late);
+      if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{}, late);
+    }
+  };
+  if (g == 0) run(std::false_type{});
+  else run(std::true_type{});
+  PP_TICK(2)
 
+  float oscale = sh.out_scale;
+  if constexpr (SC::kRanged) {
+    float sc, inv;
+    h2_scale(absmax_of_parts(ws), sc, inv);
+    oscale *= inv;
+  }
   // accumulator tiles of this wave: tix = rm*NT + nt
   constexpr int NTILE = RM * NT;
   auto store_tile = [&](auto tc, const float* part) {
@@ -208,7 +280,7 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
       const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
       float v = acc[rm][nt][q];
       if (part) v += part[q * 64];
-      if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = v * sh.out_scale;
+      if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = v * oscale;
     }
   };
   if constexpr (G == 1) {
@@ -241,52 +313,54 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
     if (g == 0) exchange(std::integral_constant<int, 0>{});
     else exchange(std::integral_constant<int, 1>{});
   }
+  PP_TICK(3)
+  if constexpr (SC::kRanged) {
+    // a basis value outside fp16's range anywhere in this tile: redo the tile in fp32
+    if (__syncthreads_or(!(lmax <= kH2Limit)))
+      fwd_tile_fp32<N, K>(x, wt, y, sh, tab, dc, b0, ROWS, blockIdx.y * 128 * NT,
+                          min(sh.O, (int)(blockIdx.y + 1) * 128 * NT));
+  }
 }
 
 // 16-input steps, padded to even so the two-group kernel splits them evenly
 int nstep_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 2; }
 
-template <int N, int K, int RM, int NT, int G>
-hipError_t launch_bf3(const float* x, const void* ws, float* y, const PPShape& sh,
+template <class SC, int N, int K, int RM, int NT, int G>
+hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y, const PPShape& sh,
                       const BasisTab& tab, const DenseCoord3& dc, int nstep, hipStream_t st) {
-  size_t lds = (size_t)G * 2 * 3 * K * 2 * 32 * RM * 16;
+  size_t lds = (size_t)G * 2 * SC::PL * K * 2 * 32 * RM * 16;
   if (G == 2) lds = std::max(lds, (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
     static bool once = false;  // per instantiation
     if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<N, K, RM, NT, G>,
+      hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       once = true;
     }
   }
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 128 * NT - 1) / (128 * NT));
-  hipLaunchKernelGGL((pp_fwd_bf3_kernel<N, K, RM, NT, G>), grid, dim3(256 * G), lds, st, x, ws, y, sh,
-                     tab, dc, nstep);
+  hipLaunchKernelGGL((pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>), grid, dim3(256 * G), lds, st, x, wt,
+                     ws, y, sh, tab, dc, nstep);
   return hipGetLastError();
 }
 
-}  // namespace
-bool pp_bf3_supported(const PPShape& sh) {
-  if (!pp_dense_supported(sh)) return false;
-  return (long)3 * sh.K * nstep_of(sh) * sh.O * 32 < (1L << 31);
-}
-
-size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
-  return (size_t)3 * sh.K * nstep_of(sh) * sh.O * 32;
-}
-
-hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                             const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+template <class SC>
+hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const int nstep = nstep_of(sh);
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
+  if constexpr (SC::kRanged) {
+    hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
+                       (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
+  }
   const long pslots = (long)sh.K * nstep * sh.O;
-  hipLaunchKernelGGL(pp_bf3_pack_w_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0, st,
-                     wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nstep);
+  hipLaunchKernelGGL(pp_split_pack_w_kernel<SC>, dim3((unsigned)((pslots + 255) / 256)), dim3(256),
+                     0, st, wt, ws, sh.I, sh.K, sh.O, nstep);
   // variant: 64-row tiles once they fill the chip (K <= 6: two groups' basis buffers fit
   // LDS); waves of 32 outs when O <= 128 so all four column waves have work.
   // PP_BF3_VARIANT=<rm><nt> overrides (tuning).
@@ -299,20 +373,42 @@ hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t*
       nt = code % 10;
     }
   }
-#define X(N_, K_)                                                                            \
-  if (sh.n == N_ && sh.K == K_) {                                                            \
-    hipError_t e = hipErrorInvalidValue;                                                     \
-    if constexpr (K_ <= 6) {                                                                 \
-      if (rm == 2 && nt == 2) e = launch_bf3<N_, K_, 2, 2, 2>(x, ws, y, sh, tab, dc, nstep, st); \
-      else if (rm == 2) e = launch_bf3<N_, K_, 2, 1, 2>(x, ws, y, sh, tab, dc, nstep, st);   \
-    }                                                                                        \
-    if (rm == 1 && nt == 2) e = launch_bf3<N_, K_, 1, 2, 2>(x, ws, y, sh, tab, dc, nstep, st); \
-    else if (rm == 1) e = launch_bf3<N_, K_, 1, 1, 2>(x, ws, y, sh, tab, dc, nstep, st);     \
-    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                   \
-    return e;                                                                                \
+#define X(N_, K_)                                                                              \
+  if (sh.n == N_ && sh.K == K_) {                                                              \
+    hipError_t e = hipErrorInvalidValue;                                                       \
+    if constexpr (K_ <= 6) {                                                                   \
+      if (rm == 2 && nt == 2)                                                                  \
+        e = launch_bf3<SC, N_, K_, 2, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, st);             \
+      else if (rm == 2)                                                                        \
+        e = launch_bf3<SC, N_, K_, 2, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, st);             \
+    }                                                                                          \
+    if (rm == 1 && nt == 2) e = launch_bf3<SC, N_, K_, 1, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, st); \
+    else if (rm == 1) e = launch_bf3<SC, N_, K_, 1, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, st); \
+    if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                     \
+    return e;                                                                                  \
   }
   PP_BF3_COMBOS(X)
 #undef X
   return hipErrorInvalidValue;
 }
 
+}  // namespace
+
+bool pp_bf3_supported(const PPShape& sh) {
+  if (!pp_dense_supported(sh)) return false;
+  return (long)3 * sh.K * nstep_of(sh) * sh.O * 32 < (1L << 31);
+}
+
+size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
+  return kWsHeader + (size_t)3 * sh.K * nstep_of(sh) * sh.O * 32;  // (fp16x2 uses 2 of 3 planes)
+}
+
+hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                             const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, st);
+}
+
+hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, st);
+}

@@ -60,6 +60,8 @@ bool pp_bf3_supported(const PPShape& sh);
 size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                              const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                            const PPShape& sh, const BasisTab& tab, hipStream_t st);
 bool pp_bf3_bwd_x_supported(const PPShape& sh);
 size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,

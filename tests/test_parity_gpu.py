@@ -163,6 +163,34 @@ def test_bf16x3_backward_input_large_rows():
     check(hip_all(x, w, gy, 3, 2, False, "bf16x3", "bf16x3", "bf16x3"), ref, "bf16x3 large")
 
 
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_fp16x2_forward(case):
+    """fp16 matrix cores, operands split 2-way, weights scaled per tensor: 1e-5 bar."""
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=12)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc, "fp16x2", "dense", "dense")
+    check(got, ref, "fp16x2")
+    print("fp16x2 y rel err", rel_err(got["y"], ref["y"]))
+    # tiny and huge weights: the per-tensor power-of-two scale keeps the pieces in range
+    for wscale in (1e-6, 3e4):
+        ref2 = oracle_all(x, w * wscale, gy, n, S, disc)
+        got2 = hip_all(x, w * wscale, gy, n, S, disc, "fp16x2", "dense", "dense")
+        assert rel_err(got2["y"], ref2["y"]) <= TOL, wscale
+
+
+def test_fp16x2_forward_out_of_range_basis():
+    """Far extrapolation: basis values beyond fp16 -> the tile is recomputed in fp32."""
+    x, w, gy = make_inputs(300, 250, 250, 3, 2, False, "normal", seed=13)
+    x[5, 17] = 700.0      # l ~ 1e6
+    x[211, 0] = -2.0e4    # l ~ 1e9
+    ref = oracle_all(x, w, gy, 3, 2, False)
+    got = hip_all(x, w, gy, 3, 2, False, "fp16x2", "dense", "dense")
+    # rows are independent: compare row-wise so the huge rows do not hide the others
+    for rows in (slice(0, 5), slice(5, 6), slice(6, 211), slice(211, 212), slice(212, 300)):
+        assert rel_err(got["y"][rows], ref["y"][rows]) <= TOL, rows
+
+
 def test_dense_rejects_inexact_layers():
     """S or length not a power of two -> the dense kernels refuse (gather path serves them)."""
     from language_interpolation_amd._lib import PPHipError
