@@ -81,7 +81,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   if (rc != PP_OK) return rc;
   const bool dense = dense_preferred(sh);
   switch (pass) {
-    case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_BF16X3 : PP_FWD_DENSE)
+    case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_FP16X2 : PP_FWD_DENSE)
                          : PP_FWD_GATHER;
     case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_BF16X3 : PP_BWD_X_DENSE)
                          : PP_BWD_X_GATHER;
