@@ -108,7 +108,8 @@ def roofline_for_hidden_layer(B, dev):
              3: "pp_fwd_bf3_kernel<bf16x3>(+pack)",
              4: "pp_fwd_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[0]]
     xname = {1: "pp_bwd_input_gather_kernel", 2: "pp_bwd_input_dense_kernel",
-             3: "pp_bwd_x_bf3_kernel(+pack)"}[methods[1]]
+             3: "pp_bwd_x_bf3_kernel<bf16x3>(+pack)",
+             4: "pp_bwd_x_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[1]]
     wname = {1: "pp_bwd_weight_atomic_kernel", 2: "pp_bwd_weight_segreduce_kernel(+sort)",
              3: "pp_bwd_weight_dense_kernel(+reduce)",
              4: "pp_bwd_w_bf3_kernel(+pack,+reduce)"}[methods[2]]

@@ -76,6 +76,8 @@ enum {
   PP_BWD_W_BF16X3 = 4, /* Phi^T x gy on bf16 MFMA, operands split 3-way (small K only) */
   PP_BWD_X_GATHER = 1,
   PP_BWD_X_DENSE = 2,
+  PP_BWD_X_FP16X2 = 4, /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor and gy per
+                          (row, 128-out chunk) by powers of two; needs a workspace */
   PP_BWD_X_BF16X3 = 3 /* gy x w^T on bf16 MFMA, operands split 3-way; needs a workspace:
                          pp_backward_input_ws_f32 */
 };

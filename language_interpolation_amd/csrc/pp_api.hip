@@ -83,7 +83,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   switch (pass) {
     case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_FP16X2 : PP_FWD_DENSE)
                          : PP_FWD_GATHER;
-    case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_BF16X3 : PP_BWD_X_DENSE)
+    case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
                          : PP_BWD_X_GATHER;
     case 2:
       if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_BF16X3 : PP_BWD_W_DENSE;
@@ -158,7 +158,7 @@ int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
 
 static int bwd_x_auto(const PPShape& sh, bool have_ws) {
   if (!dense_preferred(sh)) return PP_BWD_X_GATHER;
-  if (have_ws && pp_bf3_bwd_x_supported(sh) && sh.B >= 256) return PP_BWD_X_BF16X3;
+  if (have_ws && pp_bf3_bwd_x_supported(sh) && sh.B >= 256) return PP_BWD_X_FP16X2;
   return PP_BWD_X_DENSE;
 }
 
@@ -167,7 +167,7 @@ size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int 
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
   if (method == PP_METHOD_AUTO) method = bwd_x_auto(sh, true);
-  if (method == PP_BWD_X_BF16X3 && pp_bf3_bwd_x_supported(sh))
+  if ((method == PP_BWD_X_BF16X3 || method == PP_BWD_X_FP16X2) && pp_bf3_bwd_x_supported(sh))
     return pp_bf3_bwd_x_workspace_bytes(sh);
   return 0;
 }
@@ -187,7 +187,7 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
   make_basis(tab, n, length, nodes);
   if (method == PP_METHOD_AUTO) {
     method = bwd_x_auto(sh, workspace != nullptr);
-    if (method == PP_BWD_X_BF16X3 && workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh))
+    if (method == PP_BWD_X_FP16X2 && workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh))
       method = PP_BWD_X_DENSE;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -197,9 +197,11 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_bwd_input_dense(x, gy, w_t, gx, sh, tab, st));
   }
-  if (method == PP_BWD_X_BF16X3) {
+  if (method == PP_BWD_X_BF16X3 || method == PP_BWD_X_FP16X2) {
     if (!pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
+    if (method == PP_BWD_X_FP16X2)
+      return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, st));
     return hip_rc(pp_launch_bwd_x_bf3(x, gy, w_t, gx, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;

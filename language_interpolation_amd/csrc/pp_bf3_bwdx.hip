@@ -1,4 +1,4 @@
-// bf16x3 backward-input (scheme: pp_bf3_fwd.hip, header comment).
+// Split-operand backward-input (schemes: pp_bf3_common.h; overview: pp_bf3_fwd.hip).
 #include "pp_bf3_common.h"
 
 namespace {
@@ -13,46 +13,64 @@ namespace {
 // [half][row] x 16 B, double-buffered) and shared by the four waves; the weights come
 // pre-split from Q[plane][ostep][k][Ipad][16 outs], all K fragments of the next
 // 16-out step in flight under the 6*K*RM MFMAs of the current one.
+// Ranged scheme (fp16x2): the weights carry the tensor's power-of-two scale (pack kernel),
+// gy is scaled per (row, chunk) by a power of two taken from the chunk's row maximum
+// (LDS max, one extra barrier per chunk); when a row's scale changes between chunks the
+// wave rescales that row of its accumulators (exact), and the epilogue undoes both.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pp_bf3_pack_wo_kernel(const float* __restrict__ wt,
-                                                             u32x4* __restrict__ Q, int I, int K,
-                                                             int O, int nso, int Ipad) {
+template <class SC>
+__global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __restrict__ wt,
+                                                               void* __restrict__ ws, int I, int K,
+                                                               int O, int nso, int Ipad) {
   // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
-  // 64-byte pieces of one weight row
+  // 64-byte pieces of one weight row.  ws = header | Q.
   const long id = (long)blockIdx.x * 256 + threadIdx.x;
   if (id >= (long)Ipad * K * nso) return;
+  float scale = 1.0f, inv;
+  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
+  u32x4* Q = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + kWsHeader);
   const int t = (int)(id % nso);
   const int k = (int)((id / nso) % K);
   const int i = (int)(id / ((long)nso * K));
-  unsigned pc[3][16];
+  float v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int o = 16 * t + j;
-    const float v = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] : 0.0f;
-    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+    v[j] = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
   }
+  u32x4 lo[SC::PL], hi[SC::PL];
+  split16<SC>(v, lo, hi);
   const long per_plane = (long)nso * K * Ipad;  // slots of 32 bytes
   const long slot = ((long)t * K + k) * Ipad + i;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    Q[(p * per_plane + slot) * 2] = pack8(&pc[p][0]);
-    Q[(p * per_plane + slot) * 2 + 1] = pack8(&pc[p][8]);
+  for (int p = 0; p < SC::PL; ++p) {
+    Q[(p * per_plane + slot) * 2] = lo[p];
+    Q[(p * per_plane + slot) * 2 + 1] = hi[p];
   }
 }
 
 constexpr int kOC = 8;  // 16-out steps per gy chunk
 
 
-template <int N, int K, int RM, int VW>
+template <class SC, int N, int K, int RM, int VW>
 __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
                                                const float* __restrict__ gy,
-                                               const void* __restrict__ Q, float* __restrict__ gx,
+                                               const void* __restrict__ ws, float* __restrict__ gx,
                                                const PPShape& sh, const BasisTab& tab,
                                                const DenseCoord3& dc, int nso, int Ipad,
                                                u32x4* gyL) {
   PP_TICK(0)
+  using frag = typename SC::frag;
+  constexpr int PL = SC::PL;
   constexpr int ROWS = 32 * RM;
-  constexpr int kBufU = 3 * kOC * 2 * ROWS;
+  constexpr int kBufU = PL * kOC * 2 * ROWS;
+  // ranged scheme: per (row, chunk parity) maximum of |gy| and the scale derived from it
+  __shared__ unsigned rmaxL[2][ROWS];
+  __shared__ float2 rscL[2][ROWS];  // (scale, 1/scale)
+  if constexpr (SC::kRanged) {
+    if (threadIdx.x < 2 * ROWS) (&rmaxL[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+  }
   constexpr int FR = ROWS * 2 * kOC / 256;  // gy fragments (8 outs of one row) per thread per chunk
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -95,51 +113,68 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
       }
     }
   };
+  // (every fragment of a thread belongs to the same row: 256 % ROWS == 0)
   auto gy_publish = [&](int c, int buf) {
 #pragma unroll
     for (int m = 0; m < FR; ++m) {
       const int obase = c * (kOC * 16) + pog[m] * 8;
-      unsigned pc[3][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float v = obase + e < sh.O ? stage[m][e] : 0.0f;  // outs past O belong to the next row
-        split3(v, pc[0][e], pc[1][e], pc[2][e]);
+      for (int e = 0; e < 8; ++e)
+        if (obase + e >= sh.O) stage[m][e] = 0.0f;  // outs past O belong to the next row
+    }
+    float rs = 1.0f;
+    if constexpr (SC::kRanged) {
+      unsigned mx = 0;
+#pragma unroll
+      for (int m = 0; m < FR; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = max(mx, __float_as_uint(stage[m][e]) & 0x7fffffffu);
+      atomicMax(&rmaxL[buf][prow], mx);
+      __syncthreads();
+      float inv;
+      h2_scale(rmaxL[buf][prow], rs, inv);
+      if (threadIdx.x < ROWS) {
+        rscL[buf][prow] = make_float2(rs, inv);
+        rmaxL[buf ^ 1][prow] = 0u;  // consumed one chunk ago; next written after a barrier
       }
+    }
+#pragma unroll
+    for (int m = 0; m < FR; ++m) {
+      unsigned w[4][PL];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        SC::split_pair(stage[m][2 * e] * rs, stage[m][2 * e + 1] * rs, w[e]);
       const int t = pog[m] >> 1, hh = pog[m] & 1;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        u32x4 w;
-        w.x = (pc[p][0] >> 16) | pc[p][1];
-        w.y = (pc[p][2] >> 16) | pc[p][3];
-        w.z = (pc[p][4] >> 16) | pc[p][5];
-        w.w = (pc[p][6] >> 16) | pc[p][7];
-        gyL[buf * kBufU + ((p * kOC + t) * 2 + hh) * ROWS + prow] = w;
-      }
+      for (int p = 0; p < PL; ++p)
+        gyL[buf * kBufU + ((p * kOC + t) * 2 + hh) * ROWS + prow] =
+            u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
     }
   };
 
   // consumer
-  const rsrc_t rq = make_rsrc3(Q, (unsigned)(3u * nso * K * Ipad * 32u));
+  const rsrc_t rq = make_rsrc3(static_cast<const char*>(ws) + kWsHeader,
+                               (unsigned)((unsigned)PL * nso * K * Ipad * 32u));
   const int vq_off = ((i0 + r) * 2 + h) * 16;
   const int k_bytes = Ipad * 32;          // one (plane, ostep, k) slab
   const int t_bytes = K * k_bytes;        // one (plane, ostep)
   const int plane_bytes = nso * t_bytes;
-  auto wload = [&](int t, bf16x8 (&w)[K][3]) {
+  auto wload = [&](int t, frag (&w)[K][PL]) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PL; ++p)
         w[k][p] = __builtin_bit_cast(
-            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        rq, vq_off, p * plane_bytes + t * t_bytes + k * k_bytes, 0));
+            frag, __builtin_amdgcn_raw_buffer_load_b128(
+                      rq, vq_off, p * plane_bytes + t * t_bytes + k * k_bytes, 0));
   };
-  auto aload = [&](int buf, int tt, bf16x8 (&a)[RM][3]) {
+  auto aload = [&](int buf, int tt, frag (&a)[RM][PL]) {
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < PL; ++p)
         a[rm][p] = __builtin_bit_cast(
-            bf16x8, gyL[buf * kBufU + ((p * kOC + tt) * 2 + h) * ROWS + rm * 32 + r]);
+            frag, gyL[buf * kBufU + ((p * kOC + tt) * 2 + h) * ROWS + rm * 32 + r]);
   };
 
   f32x16 acc[K][RM];
@@ -149,17 +184,14 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
     for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[k][rm][q] = 0.0f;
-  auto mm = [&](const bf16x8 (&a)[RM][3], const bf16x8 (&w)[K][3]) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto mm = [&](const frag (&a)[RM][PL], const frag (&w)[K][PL]) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
+      for (int c = 0; c < SC::NC; ++c)
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm)
-          acc[k][rm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm][PA[c]], w[k][PB[c]],
-                                                               acc[k][rm], 0, 0, 0);
+          acc[k][rm] = SC::mfma(a[rm][SC::pa(c)], w[k][SC::pb(c)], acc[k][rm]);
   };
 
   // x of this lane's (row, input) pairs for the epilogue: issued at the start of the
@@ -178,7 +210,7 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
             __builtin_amdgcn_raw_buffer_load_b32(rx, (row * sh.I + icol) * 4, 0, 0));
       }
   };
-  bf16x8 W[2][K][3], A[2][RM][3];
+  frag W[2][K][PL], A[2][RM][PL];
   gy_load(0);
   wload(0, W[0]);
   PP_TICK(1)
@@ -191,6 +223,19 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
     if (more) gy_load(c + 1);
     else x_load();
     const int nt = min(kOC, nso - c * kOC);  // even: nso is
+    if constexpr (SC::kRanged) {
+      if (c > 0) {  // bring the accumulators to this chunk's row scales (powers of two: exact)
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rr = rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float f = rscL[buf][rr].x * rscL[buf ^ 1][rr].y;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k][rm][q] *= f;
+          }
+      }
+    }
     aload(buf, 0, A[0]);
     for (int tt = 0; tt < nt; tt += 2) {
       const int t = c * kOC + tt;
@@ -212,6 +257,12 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
     __syncthreads();
     PP_TICK(4 + 2 * (c & 1))
   }
+  float wsinv = 1.0f;
+  if constexpr (SC::kRanged) {
+    float sc;
+    h2_scale(absmax_of_parts(ws), sc, wsinv);
+  }
+  const int lastbuf = (nchunk - 1) & 1;
 
   // epilogue: lane owns input column i0 + r for 16*RM rows
   if (i < sh.I) {
@@ -243,25 +294,27 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
           }
           gsum = fmaf(d, acc[k][rm][q], gsum);
         }
+        if constexpr (SC::kRanged)
+          gsum *= rscL[lastbuf][rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h].y * wsinv;
         if (row < sh.B) gx[(size_t)row * sh.I + i] = gsum * chain;
       }
   }
   PP_TICK(7)
 }
 
-template <int N, int K, int RM>
+template <class SC, int N, int K, int RM>
 __global__ __launch_bounds__(256) void pp_bwd_x_bf3_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ gy,
                                                            const void* __restrict__ Q,
                                                            float* __restrict__ gx, PPShape sh,
                                                            BasisTab tab, DenseCoord3 dc, int nso,
                                                            int Ipad, int vw) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 gyL[];  // [2][3][kOC][2][32*RM] x 16 B
+  extern __shared__ __attribute__((aligned(16))) u32x4 gyL[];  // [2][PL][kOC][2][32*RM] x 16 B
   // vw: widest aligned vector load of a gy row (block-uniform), fixed per body so the
   // staging loads stay straight-line code
-  if (vw == 4) bwd_x_bf3_body<N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
-  else if (vw == 2) bwd_x_bf3_body<N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
-  else bwd_x_bf3_body<N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  if (vw == 4) bwd_x_bf3_body<SC, N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  else if (vw == 2) bwd_x_bf3_body<SC, N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  else bwd_x_bf3_body<SC, N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
 }
 
 }  // namespace
@@ -271,15 +324,15 @@ namespace {
 int nso_of(const PPShape& sh) { return ((sh.O + 31) / 32) * 2; }   // 16-out steps, even
 int ipad_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 32; }
 
-template <int N, int K, int RM>
+template <class SC, int N, int K, int RM>
 hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, float* gx,
                             const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
                             hipStream_t st) {
-  const size_t lds = (size_t)2 * 3 * kOC * 2 * 32 * RM * 16;
-  if (lds > 48 * 1024) {
+  const size_t lds = (size_t)2 * SC::PL * kOC * 2 * 32 * RM * 16;
+  if (lds > 40 * 1024) {
     static bool once = false;  // per instantiation
     if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<N, K, RM>,
+      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<SC, N, K, RM>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       once = true;
@@ -287,31 +340,25 @@ hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, flo
   }
   const int vw = sh.O % 4 == 0 ? 4 : (sh.O % 2 == 0 ? 2 : 1);
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (ipad_of(sh) + 127) / 128);
-  hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<N, K, RM>), grid, dim3(256), lds, st, x, gy, ws, gx, sh,
-                     tab, dc, nso_of(sh), ipad_of(sh), vw);
+  hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<SC, N, K, RM>), grid, dim3(256), lds, st, x, gy, ws, gx,
+                     sh, tab, dc, nso_of(sh), ipad_of(sh), vw);
   return hipGetLastError();
 }
-}  // namespace
 
-bool pp_bf3_bwd_x_supported(const PPShape& sh) {
-  if (!pp_dense_supported(sh)) return false;
-  return (long)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32 < (1L << 31);
-}
-
-size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh) {
-  return (size_t)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32;
-}
-
-hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
-                               void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+template <class SC>
+hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, float* gx,
+                              void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
   const int nso = nso_of(sh), Ipad = ipad_of(sh);
+  if constexpr (SC::kRanged)
+    hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
+                       (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
   const long pslots = (long)nso * sh.K * Ipad;
-  hipLaunchKernelGGL(pp_bf3_pack_wo_kernel, dim3((unsigned)((pslots + 255) / 256)), dim3(256), 0,
-                     st, wt, static_cast<u32x4*>(ws), sh.I, sh.K, sh.O, nso, Ipad);
+  hipLaunchKernelGGL(pp_split_pack_wo_kernel<SC>, dim3((unsigned)((pslots + 255) / 256)), dim3(256),
+                     0, st, wt, ws, sh.I, sh.K, sh.O, nso, Ipad);
   // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
   int rm = sh.B >= 4096 && sh.K <= 6 ? 2 : 1;
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
@@ -321,12 +368,31 @@ hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt,
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
     if constexpr (K_ <= 6) {                                                               \
-      if (rm == 2) return launch_bwd_x_bf3<N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, st);     \
+      if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, st); \
     }                                                                                      \
-    return launch_bwd_x_bf3<N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, st);                    \
+    return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, st);                \
   }
   PP_BF3_COMBOS(X)
 #undef X
   return hipErrorInvalidValue;
 }
+}  // namespace
 
+bool pp_bf3_bwd_x_supported(const PPShape& sh) {
+  if (!pp_dense_supported(sh)) return false;
+  return (long)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32 < (1L << 31);
+}
+
+size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh) {
+  return kWsHeader + (size_t)3 * nso_of(sh) * sh.K * ipad_of(sh) * 32;  // (fp16x2: 2 of 3 planes)
+}
+
+hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
+                               void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  return launch_bwd_x_split<SchemeBf3>(x, gy, wt, gx, ws, sh, tab, st);
+}
+
+hipError_t pp_launch_bwd_x_h2(const float* x, const float* gy, const float* wt, float* gx,
+                              void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  return launch_bwd_x_split<SchemeH2>(x, gy, wt, gx, ws, sh, tab, st);
+}

@@ -55,7 +55,7 @@ def test_auto_method_selection():
     assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1) == _lib.BWD_W_SORT
     assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1) == _lib.BWD_W_SORT
     # few segments, wide layer -> expanded basis on the matrix cores (cfg2 hidden, cfg1 hidden)
-    for p, want in ((0, _lib.FWD_FP16X2), (1, _lib.BWD_X_BF16X3), (2, _lib.BWD_W_DENSE)):
+    for p, want in ((0, _lib.FWD_FP16X2), (1, _lib.BWD_X_FP16X2), (2, _lib.BWD_W_DENSE)):
         assert lib.pp_auto_method(p, 256, 250, 250, 3, 2, 0) == want
         assert lib.pp_auto_method(p, 1000, 200, 200, 2, 2, 0) == want
     # K = 9 (n=5, S=2) is beyond the dense kernels -> gather

@@ -179,6 +179,32 @@ def test_fp16x2_forward(case):
         assert rel_err(got2["y"], ref2["y"]) <= TOL, wscale
 
 
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_fp16x2_backward_input(case):
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=14)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc, "dense", "fp16x2", "dense")
+    check(got, ref, "fp16x2 bwd_x")
+    # rows of very different magnitude (per-row scales), tiny overall scale
+    gy2 = gy * torch.logspace(-12, 3, B).unsqueeze(1)
+    ref2 = oracle_all(x, w * 1e-5, gy2, n, S, disc)
+    got2 = hip_all(x, w * 1e-5, gy2, n, S, disc, "dense", "fp16x2", "dense")
+    rr, gg = ref2["gx"], got2["gx"]
+    # row-wise: each row against its own largest entry
+    denom = rr.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert ((gg - rr).abs() / denom).max().item() <= TOL
+
+
+def test_fp16x2_backward_input_wide_out():
+    """More than two 128-out chunks: accumulators are rescaled between chunks."""
+    x, w, gy = make_inputs(200, 64, 600, 2, 2, False, "normal", seed=15)
+    gy[:, 300:] *= 1e4   # the row maximum moves from chunk to chunk
+    gy[:, :128] *= 1e-3
+    ref = oracle_all(x, w, gy, 2, 2, False)
+    check(hip_all(x, w, gy, 2, 2, False, "dense", "fp16x2", "dense"), ref, "fp16x2 wide")
+
+
 def test_fp16x2_forward_out_of_range_basis():
     """Far extrapolation: basis values beyond fp16 -> the tile is recomputed in fp32."""
     x, w, gy = make_inputs(300, 250, 250, 3, 2, False, "normal", seed=13)

@@ -74,7 +74,7 @@ def main():
                 by = 4 * (B * I + B * O + W)
                 rows.append((f"fwd/{m}", t, by, 2 * B * I * O * n))
             if not first:
-                for m in ("gather", "dense", "bf16x3"):
+                for m in ("gather", "dense", "bf16x3", "fp16x2"):
                     spec = PF.make_spec(n, S, disc, bwd_x_method=m)
                     try:
                         t = time_fn(lambda: PF.backward_input_raw(x, gy, w_t, spec), args.iters)
