@@ -112,6 +112,18 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
                       int discontinuous, float length, const float* nodes, float out_scale,
                       int method, void* stream);
 
+/* Pre-split weights for the fp16x2 kernels: one pass per weight UPDATE instead of one inside
+ * every forward and backward-input call.  pp_pack_weights_f32 writes both kernels' layouts
+ * (and the tensor's scale) into caller-owned memory of pp_packed_weights_bytes (0 = this
+ * layer has no fp16x2 kernels); pass that buffer as `workspace` with method
+ * PP_FWD_FP16X2 | PP_WS_PREPACKED (forward) or PP_BWD_X_FP16X2 | PP_WS_PREPACKED
+ * (backward-input): the call then only reads it.  It must be rewritten whenever w_t
+ * changes.  No reference counterpart (layout adaptor, like pp_transpose_w_f32). */
+#define PP_WS_PREPACKED 0x100
+size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous);
+int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int I, int O, int n,
+                        int S, int discontinuous, void* stream);
+
 /* Backward w.r.t. the input (A4' of SURVEY.md 8(a)):
  * gx[b,i] = out_scale * (L/(x_max-x_min)) * sum_o gy[b,o] * sum_j l'_j(xi) * w_t[i, s*stride+j, o].
  * Replaces autograd's backward through gather/einsum (loss.backward(), networks.py:164-165).

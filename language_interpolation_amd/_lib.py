@@ -17,6 +17,7 @@ PP_MAX_N = 8
 
 # method ids (include/pp_hip.h)
 METHOD_AUTO = 0
+WS_PREPACKED = 0x100
 FWD_GATHER, FWD_DENSE, FWD_BF16X3, FWD_FP16X2 = 1, 2, 3, 4
 BWD_X_GATHER, BWD_X_DENSE, BWD_X_BF16X3, BWD_X_FP16X2 = 1, 2, 3, 4
 BWD_W_ATOMIC, BWD_W_SORT, BWD_W_DENSE, BWD_W_BF16X3 = 1, 2, 3, 4
@@ -46,6 +47,8 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
     ),
+    "pp_packed_weights_bytes": (c_size_t, [c_int] * 5),
+    "pp_pack_weights_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
     "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 7),
     "pp_backward_input_ws_f32": (
         c_int,

@@ -101,6 +101,33 @@ int pp_segment_ids_f32(const float* x, int32_t* seg, int B, int I, int S, float 
   return hip_rc(pp_launch_segment_ids(x, seg, sh, (hipStream_t)stream));
 }
 
+// header | forward layout | backward-input layout (fp16x2 pieces)
+static size_t packed_weights_bytes(const PPShape& sh) {
+  return pp_h2_fwd_packed_bytes(sh) + pp_h2_bwd_x_packed_bytes(sh);
+}
+
+size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous) {
+  PPShape sh;
+  if (make_shape(sh, 256, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (!pp_bf3_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return 0;
+  return packed_weights_bytes(sh);
+}
+
+int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int I, int O, int n,
+                        int S, int discontinuous, void* stream) {
+  if (!w_t || !packed) return PP_ERR_NULL;
+  if (!aligned16(w_t) || !aligned16(packed)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, 256, I, O, n, S, discontinuous, 2.0f, 1.0f);
+  if (rc != PP_OK) return rc;
+  if (!pp_bf3_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
+  if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  pp_launch_pack_w_h2(w_t, packed, sh, st);
+  pp_launch_pack_wo_h2(w_t, packed, pp_h2_fwd_packed_bytes(sh), sh, st);
+  return hip_rc(hipGetLastError());
+}
+
 static int fwd_auto(const PPShape& sh, bool have_ws) {
   if (!dense_preferred(sh)) return PP_FWD_GATHER;
   if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_FP16X2;
@@ -128,6 +155,12 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
   if (rc != PP_OK) return rc;
   BasisTab tab;
   make_basis(tab, n, length, nodes);
+  if (method == (PP_FWD_FP16X2 | PP_WS_PREPACKED)) {
+    if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
+    if (!workspace || workspace_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
+    return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, true,
+                                   (hipStream_t)stream));
+  }
   if (method == PP_METHOD_AUTO) {
     method = fwd_auto(sh, workspace != nullptr);
     if (method == PP_FWD_FP16X2 && workspace_bytes < pp_bf3_fwd_workspace_bytes(sh))
@@ -143,7 +176,7 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_fwd_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
     if (method == PP_FWD_FP16X2)
-      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, st));
+      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, false, st));
     return hip_rc(pp_launch_fwd_bf3(x, w_t, y, seg_out, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;
@@ -185,6 +218,12 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
   if (rc != PP_OK) return rc;
   BasisTab tab;
   make_basis(tab, n, length, nodes);
+  if (method == (PP_BWD_X_FP16X2 | PP_WS_PREPACKED)) {
+    if (!pp_bf3_bwd_x_supported(sh) || !pp_bf3_supported(sh)) return PP_ERR_METHOD;
+    if (!workspace || workspace_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
+    return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, true,
+                                     pp_h2_fwd_packed_bytes(sh), (hipStream_t)stream));
+  }
   if (method == PP_METHOD_AUTO) {
     method = bwd_x_auto(sh, workspace != nullptr);
     if (method == PP_BWD_X_FP16X2 && workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh))
@@ -201,7 +240,7 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     if (!pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
     if (method == PP_BWD_X_FP16X2)
-      return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, st));
+      return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, false, 256, st));
     return hip_rc(pp_launch_bwd_x_bf3(x, gy, w_t, gx, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;

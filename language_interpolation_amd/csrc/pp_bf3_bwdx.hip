@@ -20,7 +20,8 @@ namespace {
 // ---------------------------------------------------------------------------
 template <class SC>
 __global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __restrict__ wt,
-                                                               void* __restrict__ ws, int I, int K,
+                                                               void* __restrict__ ws,
+                                                               unsigned q_off, int I, int K,
                                                                int O, int nso, int Ipad) {
   // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
   // 64-byte pieces of one weight row.  ws = header | Q.
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __re
   if (id >= (long)Ipad * K * nso) return;
   float scale = 1.0f, inv;
   if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
-  u32x4* Q = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + kWsHeader);
+  u32x4* Q = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + q_off);
   const int t = (int)(id % nso);
   const int k = (int)((id / nso) % K);
   const int i = (int)(id / ((long)nso * K));
@@ -58,7 +59,7 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
                                                const void* __restrict__ ws, float* __restrict__ gx,
                                                const PPShape& sh, const BasisTab& tab,
                                                const DenseCoord3& dc, int nso, int Ipad,
-                                               u32x4* gyL) {
+                                               unsigned q_off, u32x4* gyL) {
   PP_TICK(0)
   using frag = typename SC::frag;
   constexpr int PL = SC::PL;
@@ -153,7 +154,7 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
   };
 
   // consumer
-  const rsrc_t rq = make_rsrc3(static_cast<const char*>(ws) + kWsHeader,
+  const rsrc_t rq = make_rsrc3(static_cast<const char*>(ws) + q_off,
                                (unsigned)((unsigned)PL * nso * K * Ipad * 32u));
   const int vq_off = ((i0 + r) * 2 + h) * 16;
   const int k_bytes = Ipad * 32;          // one (plane, ostep, k) slab
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(256) void pp_bwd_x_bf3_kernel(const float* __restri
                                                            const void* __restrict__ Q,
                                                            float* __restrict__ gx, PPShape sh,
                                                            BasisTab tab, DenseCoord3 dc, int nso,
-                                                           int Ipad, int vw) {
+                                                           int Ipad, int vw, unsigned q_off) {
   extern __shared__ __attribute__((aligned(16))) u32x4 gyL[];  // [2][PL][kOC][2][32*RM] x 16 B
   // vw: widest aligned vector load of a gy row (block-uniform), fixed per body so the
   // staging loads stay straight-line code
-  if (vw == 4) bwd_x_bf3_body<SC, N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
-  else if (vw == 2) bwd_x_bf3_body<SC, N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
-  else bwd_x_bf3_body<SC, N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, gyL);
+  if (vw == 4) bwd_x_bf3_body<SC, N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
+  else if (vw == 2) bwd_x_bf3_body<SC, N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
+  else bwd_x_bf3_body<SC, N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
 }
 
 }  // namespace
@@ -327,7 +328,7 @@ int ipad_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 32; }
 template <class SC, int N, int K, int RM>
 hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, float* gx,
                             const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
-                            hipStream_t st) {
+                            unsigned q_off, hipStream_t st) {
   const size_t lds = (size_t)2 * SC::PL * kOC * 2 * 32 * RM * 16;
   if (lds > 40 * 1024) {
     static bool once = false;  // per instantiation
@@ -341,24 +342,33 @@ hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, flo
   const int vw = sh.O % 4 == 0 ? 4 : (sh.O % 2 == 0 ? 2 : 1);
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (ipad_of(sh) + 127) / 128);
   hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<SC, N, K, RM>), grid, dim3(256), lds, st, x, gy, ws, gx,
-                     sh, tab, dc, nso_of(sh), ipad_of(sh), vw);
+                     sh, tab, dc, nso_of(sh), ipad_of(sh), vw, q_off);
   return hipGetLastError();
 }
 
 template <class SC>
-hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, float* gx,
-                              void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  DenseCoord3 dc;
-  dc.w2 = 2.0f / (float)sh.S;
-  dc.inv_w = (float)sh.S / 2.0f;
-  dc.inv_len = 1.0f / sh.length;
+void pack_wo_split(const float* wt, void* ws, unsigned q_off, const PPShape& sh, bool with_absmax,
+                   hipStream_t st) {
   const int nso = nso_of(sh), Ipad = ipad_of(sh);
-  if constexpr (SC::kRanged)
+  if (SC::kRanged && with_absmax)
     hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
                        (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
   const long pslots = (long)nso * sh.K * Ipad;
   hipLaunchKernelGGL(pp_split_pack_wo_kernel<SC>, dim3((unsigned)((pslots + 255) / 256)), dim3(256),
-                     0, st, wt, ws, sh.I, sh.K, sh.O, nso, Ipad);
+                     0, st, wt, ws, q_off, sh.I, sh.K, sh.O, nso, Ipad);
+}
+
+// q_off: byte offset of Q in ws (kWsHeader for a per-call workspace; behind the forward
+// layout in a buffer written by pp_pack_weights)
+template <class SC>
+hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, float* gx,
+                              void* ws, const PPShape& sh, const BasisTab& tab, bool prepacked,
+                              unsigned q_off, hipStream_t st) {
+  DenseCoord3 dc;
+  dc.w2 = 2.0f / (float)sh.S;
+  dc.inv_w = (float)sh.S / 2.0f;
+  dc.inv_len = 1.0f / sh.length;
+  if (!prepacked) pack_wo_split<SC>(wt, ws, q_off, sh, true, st);
   // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
   int rm = sh.B >= 4096 && sh.K <= 6 ? 2 : 1;
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
@@ -368,9 +378,9 @@ hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, 
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
     if constexpr (K_ <= 6) {                                                               \
-      if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, st); \
+      if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, q_off, st); \
     }                                                                                      \
-    return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, st);                \
+    return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, q_off, st);                \
   }
   PP_BF3_COMBOS(X)
 #undef X
@@ -389,10 +399,20 @@ size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh) {
 
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
                                void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_bwd_x_split<SchemeBf3>(x, gy, wt, gx, ws, sh, tab, st);
+  return launch_bwd_x_split<SchemeBf3>(x, gy, wt, gx, ws, sh, tab, false, (unsigned)kWsHeader, st);
 }
 
 hipError_t pp_launch_bwd_x_h2(const float* x, const float* gy, const float* wt, float* gx,
-                              void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_bwd_x_split<SchemeH2>(x, gy, wt, gx, ws, sh, tab, st);
+                              void* ws, const PPShape& sh, const BasisTab& tab, bool prepacked,
+                              size_t q_off, hipStream_t st) {
+  return launch_bwd_x_split<SchemeH2>(x, gy, wt, gx, ws, sh, tab, prepacked, (unsigned)q_off, st);
+}
+
+size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh) {
+  return (size_t)2 * nso_of(sh) * sh.K * ipad_of(sh) * 32;
+}
+// backward-input layout at ws + q_off; the header's maxima must already be there
+void pp_launch_pack_wo_h2(const float* wt, void* ws, size_t q_off, const PPShape& sh,
+                          hipStream_t st) {
+  pack_wo_split<SchemeH2>(wt, ws, (unsigned)q_off, sh, false, st);
 }

@@ -347,20 +347,26 @@ hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y,
 }
 
 template <class SC>
+void pack_w_split(const float* wt, void* ws, const PPShape& sh, bool with_absmax, hipStream_t st) {
+  const int nstep = nstep_of(sh);
+  if (SC::kRanged && with_absmax)
+    hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
+                       (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
+  const long pslots = (long)sh.K * nstep * sh.O;
+  hipLaunchKernelGGL(pp_split_pack_w_kernel<SC>, dim3((unsigned)((pslots + 255) / 256)), dim3(256),
+                     0, st, wt, ws, sh.I, sh.K, sh.O, nstep);
+}
+
+template <class SC>
 hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+                            const PPShape& sh, const BasisTab& tab, bool prepacked,
+                            hipStream_t st) {
   const int nstep = nstep_of(sh);
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
-  if constexpr (SC::kRanged) {
-    hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
-                       (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
-  }
-  const long pslots = (long)sh.K * nstep * sh.O;
-  hipLaunchKernelGGL(pp_split_pack_w_kernel<SC>, dim3((unsigned)((pslots + 255) / 256)), dim3(256),
-                     0, st, wt, ws, sh.I, sh.K, sh.O, nstep);
+  if (!prepacked) pack_w_split<SC>(wt, ws, sh, true, st);
   // variant: 64-row tiles once they fill the chip (K <= 6: two groups' basis buffers fit
   // LDS); waves of 32 outs when O <= 128 so all four column waves have work.
   // PP_BF3_VARIANT=<rm><nt> overrides (tuning).
@@ -405,10 +411,19 @@ size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
 
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                              const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, st);
+  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, false, st);
 }
 
 hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, st);
+                            const PPShape& sh, const BasisTab& tab, bool prepacked,
+                            hipStream_t st) {
+  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, prepacked, st);
+}
+
+// fp16x2 forward layout only (header | P), absmax included: first half of pp_pack_weights
+size_t pp_h2_fwd_packed_bytes(const PPShape& sh) {
+  return kWsHeader + (size_t)2 * sh.K * nstep_of(sh) * sh.O * 32;
+}
+void pp_launch_pack_w_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st) {
+  pack_w_split<SchemeH2>(wt, ws, sh, true, st);
 }

@@ -90,8 +90,31 @@ def kernel_layout(w: torch.Tensor) -> torch.Tensor:
     return wt if wt.is_contiguous() else wt.contiguous()
 
 
-def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False):
-    """y (and optionally int32 segment ids) for x[B,I], w_t[I,K,O]; no autograd."""
+def pack_weights(w_t, spec: LayerSpec, B: int):
+    """Pre-split weights for the fp16x2 kernels (one pass serving this step's forward and
+    backward-input), or None when the layer / method choice does not use them."""
+    if spec.fwd_method != "auto" or spec.bwd_x_method != "auto" or B == 0:
+        return None
+    lib = _lib.load()
+    I, K, O = w_t.shape
+    args = (B, I, O, spec.n, spec.segments, int(spec.discontinuous))
+    if lib.pp_auto_method(0, *args) != _lib.FWD_FP16X2 or \
+            lib.pp_auto_method(1, *args) != _lib.BWD_X_FP16X2:
+        return None
+    nbytes = lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous))
+    if not nbytes:
+        return None
+    packed = torch.empty(nbytes, device=w_t.device, dtype=torch.uint8)
+    with torch.cuda.device(w_t.device):
+        rc = lib.pp_pack_weights_f32(_ptr(w_t), _ptr(packed), nbytes, I, O, spec.n, spec.segments,
+                                     int(spec.discontinuous), _stream(w_t.device))
+    _lib.check(rc, "pp_pack_weights_f32")
+    return packed
+
+
+def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False, packed=None):
+    """y (and optionally int32 segment ids) for x[B,I], w_t[I,K,O]; no autograd.
+    packed: buffer from pack_weights (same w_t), used instead of a per-call workspace."""
     lib = _lib.load()
     _require_gpu(x, "x")
     _require_gpu(w_t, "w")
@@ -103,10 +126,13 @@ def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False):
     seg = torch.empty(B, I, device=x.device, dtype=torch.int32) if want_seg else None
     if B == 0:
         return y, seg
-    method = _lib.FWD_METHODS[spec.fwd_method]
-    nbytes = lib.pp_forward_workspace_bytes(B, I, O, spec.n, spec.segments,
-                                            int(spec.discontinuous), method)
-    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if packed is not None:
+        method, ws, nbytes = _lib.FWD_FP16X2 | _lib.WS_PREPACKED, packed, packed.numel()
+    else:
+        method = _lib.FWD_METHODS[spec.fwd_method]
+        nbytes = lib.pp_forward_workspace_bytes(B, I, O, spec.n, spec.segments,
+                                                int(spec.discontinuous), method)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.pp_forward_ws_f32(
             _ptr(x), _ptr(w_t), _ptr(y), _ptr(seg), _ptr(ws), nbytes, B, I, O, spec.n,
@@ -116,17 +142,20 @@ def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False):
     return y, seg
 
 
-def backward_input_raw(x, gy, w_t, spec: LayerSpec):
+def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None):
     lib = _lib.load()
     B, I = x.shape
     O = w_t.shape[2]
     gx = torch.empty_like(x)
     if B == 0:
         return gx
-    method = _lib.BWD_X_METHODS[spec.bwd_x_method]
-    nbytes = lib.pp_backward_input_workspace_bytes(B, I, O, spec.n, spec.segments,
-                                                   int(spec.discontinuous), method)
-    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    if packed is not None:
+        method, ws, nbytes = _lib.BWD_X_FP16X2 | _lib.WS_PREPACKED, packed, packed.numel()
+    else:
+        method = _lib.BWD_X_METHODS[spec.bwd_x_method]
+        nbytes = lib.pp_backward_input_workspace_bytes(B, I, O, spec.n, spec.segments,
+                                                       int(spec.discontinuous), method)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.pp_backward_input_ws_f32(
             _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), _ptr(ws), nbytes, B, I, O, spec.n,
@@ -183,8 +212,12 @@ class PiecewisePolyFunction(torch.autograd.Function):
         _require_gpu(w, "w")
         x = x.contiguous()
         w_t = kernel_layout(w.detach())
-        y, _ = forward_raw(x, w_t, spec)
+        packed = pack_weights(w_t, spec, x.shape[0])
+        y, _ = forward_raw(x, w_t, spec, packed=packed)
         ctx.spec = spec
+        # the pre-split weights serve this step's backward-input too (w cannot change in
+        # between: autograd checks the saved tensor's version)
+        ctx.packed = packed if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x, w)
         return y
 
@@ -198,7 +231,7 @@ class PiecewisePolyFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = backward_input_raw(x, gy, w_t, spec)
+            gx = backward_input_raw(x, gy, w_t, spec, packed=ctx.packed)
         if ctx.needs_input_grad[1]:
             gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec)
             gw = gw_t.permute(2, 0, 1)  # logical [O,I,K]; same strides as the module's parameter

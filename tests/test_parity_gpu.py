@@ -205,6 +205,23 @@ def test_fp16x2_backward_input_wide_out():
     check(hip_all(x, w, gy, 2, 2, False, "dense", "fp16x2", "dense"), ref, "fp16x2 wide")
 
 
+def test_prepacked_weights_match_per_call_packing():
+    """pp_pack_weights_f32 + PP_WS_PREPACKED give bit-identical results to the per-call path."""
+    PF = _pf()
+    x, w, gy = make_inputs(700, 250, 128, 3, 2, False, "normal", seed=16)
+    xd, gyd = x.cuda(), gy.cuda()
+    w_t = w.permute(1, 2, 0).contiguous().cuda()
+    spec = PF.make_spec(3, 2, False)
+    packed = PF.pack_weights(w_t, spec, x.shape[0])
+    assert packed is not None
+    y1, _ = PF.forward_raw(xd, w_t, spec, packed=packed)
+    y2, _ = PF.forward_raw(xd, w_t, PF.make_spec(3, 2, False, fwd_method="fp16x2"))
+    assert torch.equal(y1, y2)
+    g1 = PF.backward_input_raw(xd, gyd, w_t, spec, packed=packed)
+    g2 = PF.backward_input_raw(xd, gyd, w_t, PF.make_spec(3, 2, False, bwd_x_method="fp16x2"))
+    assert torch.equal(g1, g2)
+
+
 def test_fp16x2_forward_out_of_range_basis():
     """Far extrapolation: basis values beyond fp16 -> the tile is recomputed in fp32."""
     x, w, gy = make_inputs(300, 250, 250, 3, 2, False, "normal", seed=13)
