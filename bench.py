@@ -112,7 +112,8 @@ def roofline_for_hidden_layer(B, dev):
              4: "pp_bwd_x_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[1]]
     wname = {1: "pp_bwd_weight_atomic_kernel", 2: "pp_bwd_weight_segreduce_kernel(+sort)",
              3: "pp_bwd_weight_dense_kernel(+reduce)",
-             4: "pp_bwd_w_bf3_kernel(+pack,+reduce)"}[methods[2]]
+             4: "pp_bwd_w_bf3_kernel<bf16x3>(+pack,+reduce)",
+             5: "pp_bwd_w_bf3_kernel<fp16x2>(+pack,+reduce)"}[methods[2]]
     times = {fname: time_kernel(fwd), xname: time_kernel(bwd_x), wname: time_kernel(bwd_w)}
     name = max(times, key=times.get)
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)

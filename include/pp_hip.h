@@ -73,6 +73,7 @@ enum {
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
+  PP_BWD_W_FP16X2 = 5, /* same on fp16 MFMA, operands split 2-way, gy scaled per (512 rows, out) */
   PP_BWD_W_BF16X3 = 4, /* Phi^T x gy on bf16 MFMA, operands split 3-way (small K only) */
   PP_BWD_X_GATHER = 1,
   PP_BWD_X_DENSE = 2,

@@ -86,7 +86,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
     case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
                          : PP_BWD_X_GATHER;
     case 2:
-      if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_BF16X3 : PP_BWD_W_DENSE;
+      if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
       return pp_sort_supported(sh) ? PP_BWD_W_SORT : PP_BWD_W_ATOMIC;
     default: return PP_ERR_METHOD;
   }
@@ -260,7 +260,7 @@ size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, 
   if (method == PP_BWD_W_SORT) return pp_sort_supported(sh) ? pp_sort_workspace_bytes(sh) : 0;
   if (method == PP_BWD_W_DENSE)
     return pp_dense_supported(sh) ? pp_dense_bwd_weight_workspace_bytes(sh) : 0;
-  if (method == PP_BWD_W_BF16X3)
+  if (method == PP_BWD_W_BF16X3 || method == PP_BWD_W_FP16X2)
     return pp_bf3_bwd_w_supported(sh) ? pp_bf3_bwd_w_workspace_bytes(sh) : 0;
   return 0;
 }
@@ -294,10 +294,13 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
       if (need && (!workspace || workspace_bytes < need)) return PP_ERR_WORKSPACE;
       return hip_rc(pp_launch_bwd_weight_dense(x, gy, gw_t, workspace, sh, tab, st));
     }
-    case PP_BWD_W_BF16X3: {
+    case PP_BWD_W_BF16X3:
+    case PP_BWD_W_FP16X2: {
       if (!pp_bf3_bwd_w_supported(sh)) return PP_ERR_METHOD;
       if (!workspace || workspace_bytes < pp_bf3_bwd_w_workspace_bytes(sh))
         return PP_ERR_WORKSPACE;
+      if (method == PP_BWD_W_FP16X2)
+        return hip_rc(pp_launch_bwd_w_h2(x, gy, gw_t, workspace, sh, tab, st));
       return hip_rc(pp_launch_bwd_w_bf3(x, gy, gw_t, workspace, sh, tab, st));
     }
     default:

@@ -1,4 +1,4 @@
-// bf16x3 backward-weight (scheme: pp_bf3_fwd.hip, header comment).
+// Split-operand backward-weight (schemes: pp_bf3_common.h; overview: pp_bf3_fwd.hip).
 #include "pp_bf3_common.h"
 
 namespace {
@@ -14,43 +14,125 @@ namespace {
 // step t+2 is written and step t+1's fragments are read under the MFMAs of step t) and
 // every wave runs 6*K*NT MFMAs into its K x NT accumulators.  Per-chunk partial sums go
 // to the workspace and are added in a fixed order by pp_dense_reduce_kernel.
+// Ranged scheme (fp16x2): gy is scaled by a power of two per (block of 32 steps = 512
+// rows, out column), taken from that block's column maximum inside the pack kernel
+// (scales in the workspace header); when the scale of its columns changes from one block
+// of rows to the next a wave rescales its accumulators (exact), the store undoes the last
+// scale; a row chunk whose basis leaves fp16's range is recomputed in fp32 by its block.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pp_bf3_pack_gy_kernel(const float* __restrict__ gy,
-                                                             u32x4* __restrict__ G, int B, int O,
-                                                             int Opad, int nbs) {
+constexpr int kSB = 32;  // steps per scale block
+
+// ranged pack: block = (scale block, 64 out columns); 4 step groups x 64 columns; every
+// thread holds its kSB/4 steps x 16 rows in registers between the max and the split pass
+template <class SC>
+__global__ __launch_bounds__(256) void pp_split_pack_gy_ranged_kernel(
+    const float* __restrict__ gy, float2* __restrict__ gscale, u32x4* __restrict__ G, int B, int O,
+    int Opad, int nbs) {
+  __shared__ unsigned cmax[64];
+  const int sb = blockIdx.x;
+  const int oc = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int o = blockIdx.y * 64 + oc;
+  if (threadIdx.x < 64) cmax[threadIdx.x] = 0u;
+  __syncthreads();
+  constexpr int PER = kSB / 4;
+  float v[PER][16];
+  unsigned mx = 0;
+#pragma unroll
+  for (int m = 0; m < PER; ++m) {
+    const int t = sb * kSB + tg + 4 * m;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int b = 16 * t + j;
+      v[m][j] = (b < B && o < O) ? gy[(size_t)b * O + o] : 0.0f;
+      mx = max(mx, __float_as_uint(v[m][j]) & 0x7fffffffu);
+    }
+  }
+  atomicMax(&cmax[oc], mx);
+  __syncthreads();
+  float sc, inv;
+  h2_scale(cmax[oc], sc, inv);
+  if (o >= Opad) return;
+  if (tg == 0) gscale[(size_t)sb * Opad + o] = make_float2(sc, inv);
+#pragma unroll
+  for (int m = 0; m < PER; ++m) {
+    const int t = sb * kSB + tg + 4 * m;
+    if (t >= nbs) continue;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[m][j] *= sc;
+    u32x4 lo[SC::PL], hi[SC::PL];
+    split16<SC>(v[m], lo, hi);
+#pragma unroll
+    for (int p = 0; p < SC::PL; ++p) {
+      G[(((size_t)p * nbs + t) * Opad + o) * 2] = lo[p];
+      G[(((size_t)p * nbs + t) * Opad + o) * 2 + 1] = hi[p];
+    }
+  }
+}
+
+// plain fp32 recomputation of a block's partial tile (inputs i0..i0+32, outs o_lo..o_hi,
+// rows cbeg..cend): the rare way out when the ranged scheme met a basis value beyond fp16
+template <int N, int K>
+__device__ __forceinline__ void bwd_w_tile_fp32(const float* __restrict__ x,
+                                                const float* __restrict__ gy,
+                                                float* __restrict__ dst, const PPShape& sh,
+                                                const BasisTab& tab, const DenseCoord3& dc, int i0,
+                                                int o_lo, int o_hi, int cbeg, int cend,
+                                                float scale) {
+  const int ncol = o_hi - o_lo;
+  for (int idx = threadIdx.x; idx < 32 * ncol; idx += blockDim.x) {
+    const int i = i0 + idx / ncol, col = o_lo + idx % ncol;
+    if (i >= sh.I) continue;
+    float a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = 0.0f;
+    for (int b = cbeg; b < cend; ++b) {
+      float phi[K];
+      phi3<N, K>(x[(size_t)b * sh.I + i], true, sh, tab, dc, phi);
+      const float g = gy[(size_t)b * sh.O + col];
+#pragma unroll
+      for (int k = 0; k < K; ++k) a[k] = fmaf(phi[k], g, a[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dst[((size_t)i * K + k) * sh.O + col] = a[k] * scale;
+  }
+}
+
+template <class SC>
+__global__ __launch_bounds__(256) void pp_split_pack_gy_kernel(const float* __restrict__ gy,
+                                                               u32x4* __restrict__ G, int B, int O,
+                                                               int Opad, int nbs) {
   const long id = (long)blockIdx.x * 256 + threadIdx.x;
   if (id >= (long)nbs * Opad) return;
   const int o = (int)(id % Opad);
   const int t = (int)(id / Opad);
-  unsigned pc[3][16];
+  float v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int b = 16 * t + j;
-    const float v = (b < B && o < O) ? gy[(size_t)b * O + o] : 0.0f;
-    split3(v, pc[0][j], pc[1][j], pc[2][j]);
+    v[j] = (b < B && o < O) ? gy[(size_t)b * O + o] : 0.0f;
   }
+  u32x4 lo[SC::PL], hi[SC::PL];
+  split16<SC>(v, lo, hi);
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      u32x4 w;
-      w.x = (pc[p][8 * hh + 0] >> 16) | pc[p][8 * hh + 1];
-      w.y = (pc[p][8 * hh + 2] >> 16) | pc[p][8 * hh + 3];
-      w.z = (pc[p][8 * hh + 4] >> 16) | pc[p][8 * hh + 5];
-      w.w = (pc[p][8 * hh + 6] >> 16) | pc[p][8 * hh + 7];
-      G[(((size_t)p * nbs + t) * Opad + o) * 2 + hh] = w;
-    }
+  for (int p = 0; p < SC::PL; ++p) {
+    G[(((size_t)p * nbs + t) * Opad + o) * 2] = lo[p];
+    G[(((size_t)p * nbs + t) * Opad + o) * 2 + 1] = hi[p];
+  }
 }
 
-template <int N, int K, int NT>
+template <class SC, int N, int K, int NT>
 __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ gy,
+                                                           const float2* __restrict__ gscale,
                                                            const void* __restrict__ G,
                                                            float* __restrict__ out, PPShape sh,
                                                            BasisTab tab, DenseCoord3 dc,
                                                            int rows_per_chunk, int nbs, int Opad,
                                                            float scale) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [3 buf][3 plane][K][2][32] x 16 B
-  constexpr int kBufU = 3 * K * 2 * 32;
+  using frag = typename SC::frag;
+  constexpr int PL = SC::PL;
+  extern __shared__ __attribute__((aligned(16))) u32x4 phiL[];  // [3 buf][PL][K][2][32] x 16 B
+  constexpr int kBufU = PL * K * 2 * 32;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
@@ -74,43 +156,42 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
     xv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, t * xstep, 0));
     xv[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx + xrow, t * xstep, 0));
   };
+  float lmax = 0.0f;  // ranged schemes: largest |basis value| this lane produced
   auto produce = [&](int t, int buf, const float (&xv)[2]) {
     const int row = cbeg + 16 * t + 2 * rp;
     float pa[K], pb[K];
-    phi3<N, K>(xv[0], row < cend, sh, tab, dc, pa);
-    phi3<N, K>(xv[1], row + 1 < cend, sh, tab, dc, pb);
+    phi3<N, K>(xv[0], row < cend, sh, tab, dc, pa, SC::kRanged ? &lmax : nullptr);
+    phi3<N, K>(xv[1], row + 1 < cend, sh, tab, dc, pb, SC::kRanged ? &lmax : nullptr);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      unsigned a1, a2, a3, c1, c2, c3;
-      split3(pa[k], a1, a2, a3);
-      split3(pb[k], c1, c2, c3);
+      unsigned w[PL];
+      SC::split_pair(pa[k], pb[k], w);
       const int base = (buf * kBufU + k * 64) * 4 + pw_base;
-      phiW[base] = (a1 >> 16) | c1;
-      phiW[base + K * 64 * 4] = (a2 >> 16) | c2;
-      phiW[base + 2 * K * 64 * 4] = (a3 >> 16) | c3;
+#pragma unroll
+      for (int p = 0; p < PL; ++p) phiW[base + p * K * 64 * 4] = w[p];
     }
   };
   // consumer
-  const rsrc_t rg = make_rsrc3(G, (unsigned)(3u * nbs * Opad * 32u));
+  const rsrc_t rg = make_rsrc3(G, (unsigned)((unsigned)PL * nbs * Opad * 32u));
   int vcol[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) vcol[nt] = (min(o0 + nt * 32 + r, Opad - 1) * 2 + h) * 16;
   const int gstep = Opad * 32, gplane = nbs * gstep;
-  auto bload = [&](int t, bf16x8 (&bf)[3][NT]) {
+  auto bload = [&](int t, frag (&bf)[PL][NT]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < PL; ++p)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         bf[p][nt] = __builtin_bit_cast(
-            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rg, vcol[nt],
-                                                          p * gplane + (t0 + t) * gstep, 0));
+            frag, __builtin_amdgcn_raw_buffer_load_b128(rg, vcol[nt],
+                                                        p * gplane + (t0 + t) * gstep, 0));
   };
-  auto aload = [&](int buf, bf16x8 (&a)[K][3]) {
+  auto aload = [&](int buf, frag (&a)[K][PL]) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[k][p] = __builtin_bit_cast(bf16x8, phiL[buf * kBufU + ((p * K + k) * 2 + h) * 32 + r]);
+      for (int p = 0; p < PL; ++p)
+        a[k][p] = __builtin_bit_cast(frag, phiL[buf * kBufU + ((p * K + k) * 2 + h) * 32 + r]);
   };
   f32x16 acc[K][NT];
 #pragma unroll
@@ -119,21 +200,44 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[k][nt][q] = 0.0f;
-  auto mm = [&](const bf16x8 (&a)[K][3], const bf16x8 (&bf)[3][NT]) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto mm = [&](const frag (&a)[K][PL], const frag (&bf)[PL][NT]) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int c = 0; c < 6; ++c)
+      for (int c = 0; c < SC::NC; ++c)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[k][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k][PA[c]], bf[PB[c]][nt],
-                                                               acc[k][nt], 0, 0, 0);
+          acc[k][nt] = SC::mfma(a[k][SC::pa(c)], bf[SC::pb(c)][nt], acc[k][nt]);
+  };
+  // ranged: scale of this lane's columns in the current block of kSB steps
+  int ccol[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) ccol[nt] = min(o0 + nt * 32 + r, Opad - 1);
+  float2 csc[NT];
+  int sb_cur = t0 / kSB;
+  if constexpr (SC::kRanged) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) csc[nt] = gscale[(size_t)sb_cur * Opad + ccol[nt]];
+  }
+  auto rescale = [&](int t) {  // entering step t: a new scale block?
+    const int sb = (t0 + t) / kSB;
+    if (sb != sb_cur) {  // block-uniform
+      sb_cur = sb;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float2 nsc = gscale[(size_t)sb * Opad + ccol[nt]];
+        const float f = nsc.x * csc[nt].y;  // new scale / old scale: a power of two
+        csc[nt] = nsc;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[k][nt][q] *= f;
+      }
+    }
   };
 
   float xr[2][2];
-  bf16x8 Bf[3][3][NT], A[2][K][3];
+  frag Bf[3][PL][NT], A[2][K][PL];
   {
     float x0[2], x1[2];
     xload(0, x0);
@@ -151,6 +255,7 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
   // under the MFMAs of step t.  Steps past the chunk evaluate to zero (valid flags).
   auto stepfn = [&](int t, auto jc) {
     constexpr int J = decltype(jc)::value;
+    if constexpr (SC::kRanged) rescale(t);
     xload(t + 3, xr[(J + 1) & 1]);
     bload(t + 2, Bf[(J + 2) % 3]);
     aload((J + 1) % 3, A[(J + 1) & 1]);
@@ -166,20 +271,28 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
     if (t + 4 < nst) stepfn(t + 4, std::integral_constant<int, 4>{});
     if (t + 5 < nst) stepfn(t + 5, std::integral_constant<int, 5>{});
   }
-  if (o0 >= sh.O) return;  // wave-uniform: this wave ran on clamped columns
   float* dst = out + (size_t)chunk * sh.I * K * sh.O;
+  if (o0 < sh.O) {  // wave-uniform: else this wave ran on clamped columns
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = o0 + nt * 32 + r;
-    if (col < sh.O) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = o0 + nt * 32 + r;
+      float cs = scale;
+      if constexpr (SC::kRanged) cs *= csc[nt].y;
+      if (col < sh.O) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;  // input index
-          if (row < sh.I) dst[((size_t)row * K + k) * sh.O + col] = acc[k][nt][q] * scale;
-        }
+          for (int q = 0; q < 16; ++q) {
+            const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;  // input index
+            if (row < sh.I) dst[((size_t)row * K + k) * sh.O + col] = acc[k][nt][q] * cs;
+          }
+      }
     }
+  }
+  if constexpr (SC::kRanged) {
+    if (__syncthreads_or(!(lmax <= kH2Limit)))
+      bwd_w_tile_fp32<N, K>(x, gy, dst, sh, tab, dc, i0, blockIdx.z * 128 * NT,
+                            min(sh.O, (int)(blockIdx.z + 1) * 128 * NT), cbeg, cend, scale);
   }
 }
 
@@ -188,8 +301,8 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
 // ---- backward-weight ----
 namespace {
 struct WPlan3 {
-  int nt, ocols, nchunk, rows_per_chunk, nbs, opad;
-  size_t g_bytes, part_bytes;
+  int nt, ocols, nchunk, rows_per_chunk, nbs, opad, nsb;
+  size_t sc_bytes, g_bytes, part_bytes;
 };
 
 WPlan3 wplan3(const PPShape& sh) {
@@ -197,7 +310,7 @@ WPlan3 wplan3(const PPShape& sh) {
   // K x NT accumulators of 16 registers per wave; 32-out waves when O <= 128 so that
   // all four column waves have work
   p.nt = (sh.K <= 6 && sh.O > 128) ? 2 : 1;
-  p.opad = ((sh.O + 31) / 32) * 32;
+  p.opad = ((sh.O + 63) / 64) * 64;
   p.ocols = (sh.O + 128 * p.nt - 1) / (128 * p.nt);
   const int tiles = ((sh.I + 31) / 32) * p.ocols;
   int target = 256;
@@ -210,29 +323,71 @@ WPlan3 wplan3(const PPShape& sh) {
   p.rows_per_chunk = rpc;
   p.nchunk = (sh.B + rpc - 1) / rpc;
   p.nbs = (sh.B + 15) / 16;  // (steps prefetched past the end read out of range: zeros, unused)
-  p.g_bytes = (size_t)3 * p.nbs * p.opad * 32;
+  p.nsb = (p.nbs + kSB - 1) / kSB;
+  p.sc_bytes = (((size_t)p.nsb * p.opad * sizeof(float2)) + 255) / 256 * 256;
+  p.g_bytes = (size_t)3 * p.nbs * p.opad * 32;  // (fp16x2 uses 2 of the 3 planes)
   p.part_bytes = p.nchunk > 1 ? (size_t)p.nchunk * sh.I * sh.K * sh.O * sizeof(float) : 0;
   return p;
 }
 
-template <int N, int K, int NT>
-hipError_t launch_bwd_w_bf3(const float* x, const void* G, float* out, const PPShape& sh,
-                            const BasisTab& tab, const DenseCoord3& dc, const WPlan3& p,
-                            float scale, hipStream_t st) {
-  const size_t lds = (size_t)3 * 3 * K * 2 * 32 * 16;
+template <class SC, int N, int K, int NT>
+hipError_t launch_bwd_w_bf3(const float* x, const float* gy, const void* ws, float* out,
+                            const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
+                            const WPlan3& p, float scale, hipStream_t st) {
+  const size_t lds = (size_t)3 * SC::PL * K * 2 * 32 * 16;
   if (lds > 48 * 1024) {
     static bool once = false;  // per instantiation
     if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_w_bf3_kernel<N, K, NT>,
+      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_w_bf3_kernel<SC, N, K, NT>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       once = true;
     }
   }
   dim3 grid((sh.I + 31) / 32, p.nchunk, p.ocols);
-  hipLaunchKernelGGL((pp_bwd_w_bf3_kernel<N, K, NT>), grid, dim3(256), lds, st, x, G, out, sh, tab,
-                     dc, p.rows_per_chunk, p.nbs, p.opad, scale);
+  const char* base = static_cast<const char*>(ws);
+  hipLaunchKernelGGL((pp_bwd_w_bf3_kernel<SC, N, K, NT>), grid, dim3(256), lds, st, x, gy,
+                     reinterpret_cast<const float2*>(base), (const void*)(base + p.sc_bytes), out,
+                     sh, tab, dc, p.rows_per_chunk, p.nbs, p.opad, scale);
   return hipGetLastError();
+}
+
+template <class SC>
+hipError_t launch_bwd_w_split(const float* x, const float* gy, float* gwt, void* ws,
+                              const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  DenseCoord3 dc;
+  dc.w2 = 2.0f / (float)sh.S;
+  dc.inv_w = (float)sh.S / 2.0f;
+  dc.inv_len = 1.0f / sh.length;
+  const WPlan3 p = wplan3(sh);
+  char* base = static_cast<char*>(ws);
+  u32x4* G = reinterpret_cast<u32x4*>(base + p.sc_bytes);
+  if constexpr (SC::kRanged) {
+    hipLaunchKernelGGL(pp_split_pack_gy_ranged_kernel<SC>, dim3(p.nsb, p.opad / 64), dim3(256), 0,
+                       st, gy, reinterpret_cast<float2*>(base), G, sh.B, sh.O, p.opad, p.nbs);
+  } else {
+    const long nthr = (long)p.nbs * p.opad;
+    hipLaunchKernelGGL(pp_split_pack_gy_kernel<SC>, dim3((unsigned)((nthr + 255) / 256)), dim3(256),
+                       0, st, gy, G, sh.B, sh.O, p.opad, p.nbs);
+  }
+  float* part = reinterpret_cast<float*>(base + p.sc_bytes + p.g_bytes);
+  float* out = p.nchunk > 1 ? part : gwt;
+  const float scale = p.nchunk > 1 ? 1.0f : sh.out_scale;
+#define X(N_, K_)                                                                          \
+  if (sh.n == N_ && sh.K == K_) {                                                          \
+    hipError_t e = hipErrorInvalidValue;                                                   \
+    if constexpr (K_ <= 6) {                                                               \
+      if (p.nt == 2)                                                                       \
+        e = launch_bwd_w_bf3<SC, N_, K_, 2>(x, gy, ws, out, sh, tab, dc, p, scale, st);    \
+    }                                                                                      \
+    if (p.nt == 1) e = launch_bwd_w_bf3<SC, N_, K_, 1>(x, gy, ws, out, sh, tab, dc, p, scale, st); \
+    if (e != hipSuccess || p.nchunk <= 1) return e;                                        \
+    pp_launch_chunk_reduce(part, gwt, (long)sh.I * sh.K * sh.O, p.nchunk, sh.out_scale, st); \
+    return hipGetLastError();                                                              \
+  }
+  PP_BF3_COMBOS(X)
+#undef X
+  return hipErrorInvalidValue;
 }
 }  // namespace
 
@@ -244,35 +399,15 @@ bool pp_bf3_bwd_w_supported(const PPShape& sh) {
 
 size_t pp_bf3_bwd_w_workspace_bytes(const PPShape& sh) {
   const WPlan3 p = wplan3(sh);
-  return p.g_bytes + p.part_bytes;
+  return p.sc_bytes + p.g_bytes + p.part_bytes;
 }
 
 hipError_t pp_launch_bwd_w_bf3(const float* x, const float* gy, float* gwt, void* ws,
                                const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  DenseCoord3 dc;
-  dc.w2 = 2.0f / (float)sh.S;
-  dc.inv_w = (float)sh.S / 2.0f;
-  dc.inv_len = 1.0f / sh.length;
-  const WPlan3 p = wplan3(sh);
-  const long nthr = (long)p.nbs * p.opad;
-  hipLaunchKernelGGL(pp_bf3_pack_gy_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st,
-                     gy, static_cast<u32x4*>(ws), sh.B, sh.O, p.opad, p.nbs);
-  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + p.g_bytes);
-  float* out = p.nchunk > 1 ? part : gwt;
-  const float scale = p.nchunk > 1 ? 1.0f : sh.out_scale;
-#define X(N_, K_)                                                                          \
-  if (sh.n == N_ && sh.K == K_) {                                                          \
-    hipError_t e;                                                                          \
-    e = hipErrorInvalidValue;                                                              \
-    if constexpr (K_ <= 6) {                                                               \
-      if (p.nt == 2) e = launch_bwd_w_bf3<N_, K_, 2>(x, ws, out, sh, tab, dc, p, scale, st); \
-    }                                                                                      \
-    if (p.nt == 1) e = launch_bwd_w_bf3<N_, K_, 1>(x, ws, out, sh, tab, dc, p, scale, st); \
-    if (e != hipSuccess || p.nchunk <= 1) return e;                                        \
-    pp_launch_chunk_reduce(part, gwt, (long)sh.I * sh.K * sh.O, p.nchunk, sh.out_scale, st); \
-    return hipGetLastError();                                                              \
-  }
-  PP_BF3_COMBOS(X)
-#undef X
-  return hipErrorInvalidValue;
+  return launch_bwd_w_split<SchemeBf3>(x, gy, gwt, ws, sh, tab, st);
+}
+
+hipError_t pp_launch_bwd_w_h2(const float* x, const float* gy, float* gwt, void* ws,
+                              const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  return launch_bwd_w_split<SchemeH2>(x, gy, gwt, ws, sh, tab, st);
 }

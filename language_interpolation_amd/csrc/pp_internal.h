@@ -79,3 +79,5 @@ bool pp_bf3_bwd_w_supported(const PPShape& sh);
 size_t pp_bf3_bwd_w_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_w_bf3(const float* x, const float* gy, float* gwt, void* ws,
                                const PPShape& sh, const BasisTab& tab, hipStream_t st);
+hipError_t pp_launch_bwd_w_h2(const float* x, const float* gy, float* gwt, void* ws,
+                              const PPShape& sh, const BasisTab& tab, hipStream_t st);

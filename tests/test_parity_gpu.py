@@ -205,6 +205,38 @@ def test_fp16x2_backward_input_wide_out():
     check(hip_all(x, w, gy, 2, 2, False, "dense", "fp16x2", "dense"), ref, "fp16x2 wide")
 
 
+@pytest.mark.parametrize("case", DENSE_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_fp16x2_backward_weight(case):
+    disc, n, S, I, O, B, dist = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=17)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc, "dense", "dense", "fp16x2"), ref, "fp16x2 bwd_w")
+    # tiny gradients (the usual case: gy ~ 1/(B*O)) and columns of very different size
+    gy2 = gy * 1e-9 * torch.logspace(0, 6, O).unsqueeze(0)
+    ref2 = oracle_all(x, w, gy2, n, S, disc)
+    got2 = hip_all(x, w, gy2, n, S, disc, "dense", "dense", "fp16x2")
+    rr, gg = ref2["gw"], got2["gw"]          # [O, I, K]: column-wise bar
+    denom = rr.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-38)
+    assert ((gg - rr).abs() / denom).max().item() <= TOL
+
+
+def test_fp16x2_backward_weight_row_blocks_and_range():
+    """Several 512-row scale blocks with different magnitudes (accumulators rescaled in
+    between) and a basis value beyond fp16 (that block recomputes its tile in fp32)."""
+    x, w, gy = make_inputs(9000, 96, 250, 3, 2, False, "normal", seed=18)
+    gy[:512] *= 1e-6
+    gy[1024:2048] *= 1e5
+    gy[4000:] *= 3e-3
+    ref = oracle_all(x, w, gy, 3, 2, False)
+    check(hip_all(x, w, gy, 3, 2, False, "fp16x2", "fp16x2", "fp16x2"), ref, "fp16x2 blocks")
+    x[77, 40] = 900.0   # basis ~ 1e6 in input tile 1
+    ref = oracle_all(x, w, gy, 3, 2, False)
+    got = hip_all(x, w, gy, 3, 2, False, "dense", "dense", "fp16x2")
+    rr, gg = ref["gw"], got["gw"]
+    for sl in (slice(0, 32), slice(32, 64), slice(64, 96)):   # per 32-input tile
+        assert rel_err(gg[:, sl], rr[:, sl]) <= TOL, sl
+
+
 def test_prepacked_weights_match_per_call_packing():
     """pp_pack_weights_f32 + PP_WS_PREPACKED give bit-identical results to the per-call path."""
     PF = _pf()
