@@ -123,8 +123,7 @@ int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int
   if (!pp_bf3_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
   if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  pp_launch_pack_w_h2(w_t, packed, sh, st);
-  pp_launch_pack_wo_h2(w_t, packed, pp_h2_fwd_packed_bytes(sh), sh, st);
+  pp_launch_pack_both_h2(w_t, packed, sh, st);
   return hip_rc(hipGetLastError());
 }
 

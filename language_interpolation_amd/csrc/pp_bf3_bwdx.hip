@@ -23,31 +23,7 @@ __global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __re
                                                                void* __restrict__ ws,
                                                                unsigned q_off, int I, int K,
                                                                int O, int nso, int Ipad) {
-  // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
-  // 64-byte pieces of one weight row.  ws = header | Q.
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  if (id >= (long)Ipad * K * nso) return;
-  float scale = 1.0f, inv;
-  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
-  u32x4* Q = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + q_off);
-  const int t = (int)(id % nso);
-  const int k = (int)((id / nso) % K);
-  const int i = (int)(id / ((long)nso * K));
-  float v[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int o = 16 * t + j;
-    v[j] = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
-  }
-  u32x4 lo[SC::PL], hi[SC::PL];
-  split16<SC>(v, lo, hi);
-  const long per_plane = (long)nso * K * Ipad;  // slots of 32 bytes
-  const long slot = ((long)t * K + k) * Ipad + i;
-#pragma unroll
-  for (int p = 0; p < SC::PL; ++p) {
-    Q[(p * per_plane + slot) * 2] = lo[p];
-    Q[(p * per_plane + slot) * 2 + 1] = hi[p];
-  }
+  pack_wo_body<SC>((long)blockIdx.x * 256 + threadIdx.x, wt, ws, q_off, I, K, O, nso, Ipad);
 }
 
 constexpr int kOC = 8;  // 16-out steps per gy chunk
@@ -211,9 +187,14 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
             __builtin_amdgcn_raw_buffer_load_b32(rx, (row * sh.I + icol) * 4, 0, 0));
       }
   };
-  frag W[2][K][PL], A[2][RM][PL];
+  // W fragment sets: D steps of prefetch distance.  (D = 2 was tried for the fp16 scheme,
+  // whose 16-out step is shorter than an L2 round trip: 4 sets + 160 accumulators spill.)
+  constexpr int D = 1;
+  constexpr int NWS = 2 * D;
+  frag W[NWS][K][PL], A[2][RM][PL];
   gy_load(0);
-  wload(0, W[0]);
+#pragma unroll
+  for (int u = 0; u < D; ++u) wload(u, W[u]);
   PP_TICK(1)
   gy_publish(0, 0);
   __syncthreads();
@@ -238,20 +219,26 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
       }
     }
     aload(buf, 0, A[0]);
-    for (int tt = 0; tt < nt; tt += 2) {
-      const int t = c * kOC + tt;
-      // sched_barrier: keep the next step's loads ahead of this step's MFMAs (the
-      // scheduler otherwise sinks them to their first use to save registers)
-      wload(t + 1, W[1]);
-      aload(buf, tt + 1, A[1]);
+    // one step: W of step t+D and A of step t+1 are issued, then the MFMAs of step t.
+    // sched_barrier keeps the loads ahead of the MFMAs (the scheduler otherwise sinks them
+    // to their first use to save registers).  kOC % NWS == 0: set index = tt % NWS.
+    auto step = [&](int tt, auto uc) {
+      constexpr int U = decltype(uc)::value;
+      wload(c * kOC + tt + D, W[(U + D) % NWS]);
+      aload(buf, min(tt + 1, kOC - 1), A[(U + 1) & 1]);  // (past the chunk: a harmless re-read)
       __builtin_amdgcn_sched_barrier(0);
-      mm(A[0], W[0]);
+      mm(A[U & 1], W[U]);
       __builtin_amdgcn_sched_barrier(0);
-      wload(t + 2, W[0]);
-      aload(buf, min(tt + 2, kOC - 1), A[0]);  // (past the chunk: a harmless re-read)
-      __builtin_amdgcn_sched_barrier(0);
-      mm(A[1], W[1]);
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int tt = 0; tt < nt; tt += NWS) {
+      step(tt, std::integral_constant<int, 0>{});
+      step(tt + 1, std::integral_constant<int, 1>{});
+      if constexpr (NWS == 4) {
+        if (tt + 2 < nt) {  // nt is even
+          step(tt + 2, std::integral_constant<int, 2>{});
+          step(tt + 3, std::integral_constant<int, 3>{});
+        }
+      }
     }
     PP_TICK(3 + 2 * (c & 1))
     if (more) gy_publish(c + 1, buf ^ 1);
@@ -282,8 +269,8 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
         const int s = (__builtin_fabsf(t) < 9.2e18f) ? si : 0;
         const float x_min = (float)s * dc.w2 - 1.0f;
         const float xi = sh.length * ((xq - x_min) * dc.inv_w) - sh.half;
-        float l[N], dl[N];
-        pp_lagrange_d<N>(xi, tab, l, dl);
+        float dl[N];
+        pp_lagrange_dl<N>(xi, tab, dl);
         float gsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -410,9 +397,4 @@ hipError_t pp_launch_bwd_x_h2(const float* x, const float* gy, const float* wt, 
 
 size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh) {
   return (size_t)2 * nso_of(sh) * sh.K * ipad_of(sh) * 32;
-}
-// backward-input layout at ws + q_off; the header's maxima must already be there
-void pp_launch_pack_wo_h2(const float* wt, void* ws, size_t q_off, const PPShape& sh,
-                          hipStream_t st) {
-  pack_wo_split<SchemeH2>(wt, ws, (unsigned)q_off, sh, false, st);
 }

@@ -215,6 +215,66 @@ __device__ __forceinline__ unsigned absmax_of_parts(const void* hdr) {
   return m;
 }
 
+// P[plane][k][step][out][16]: 16-bit pieces of w_t[i = 16*step + j][k][out] (times the
+// tensor's power-of-two scale for a ranged scheme).  One thread per (k, step, out): 16
+// reads coalesced over `out`, two 16-byte stores per plane.  ws = header | P.
+template <class SC>
+__device__ __forceinline__ void pack_w_body(long id, const float* __restrict__ wt,
+                                            void* __restrict__ ws, int I, int K, int O, int nstep) {
+  const long per_plane = (long)K * nstep * O;  // in (k, step, out) slots of 32 bytes
+  if (id >= per_plane) return;
+  float scale = 1.0f, inv;
+  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
+  u32x4* P = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + kWsHeader);
+  const int o = (int)(id % O);
+  const int s = (int)((id / O) % nstep);
+  const int k = (int)(id / ((long)O * nstep));
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = 16 * s + j;
+    v[j] = i < I ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
+  }
+  u32x4 lo[SC::PL], hi[SC::PL];
+  split16<SC>(v, lo, hi);
+#pragma unroll
+  for (int p = 0; p < SC::PL; ++p) {
+    P[(p * per_plane + id) * 2] = lo[p];
+    P[(p * per_plane + id) * 2 + 1] = hi[p];
+  }
+}
+
+// Q[plane][ostep][k][Ipad][16 outs] at ws + q_off: the backward-input weight layout.
+template <class SC>
+__device__ __forceinline__ void pack_wo_body(long id, const float* __restrict__ wt,
+                                             void* __restrict__ ws, unsigned q_off, int I, int K,
+                                             int O, int nso, int Ipad) {
+  // one thread per (i, k, ostep), ostep fastest: consecutive threads read consecutive
+  // 64-byte pieces of one weight row.  ws = header | Q.
+  if (id >= (long)Ipad * K * nso) return;
+  float scale = 1.0f, inv;
+  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
+  u32x4* Q = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + q_off);
+  const int t = (int)(id % nso);
+  const int k = (int)((id / nso) % K);
+  const int i = (int)(id / ((long)nso * K));
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int o = 16 * t + j;
+    v[j] = (i < I && o < O) ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
+  }
+  u32x4 lo[SC::PL], hi[SC::PL];
+  split16<SC>(v, lo, hi);
+  const long per_plane = (long)nso * K * Ipad;  // slots of 32 bytes
+  const long slot = ((long)t * K + k) * Ipad + i;
+#pragma unroll
+  for (int p = 0; p < SC::PL; ++p) {
+    Q[(p * per_plane + slot) * 2] = lo[p];
+    Q[(p * per_plane + slot) * 2 + 1] = hi[p];
+  }
+}
+
 // developer builds (-DPP_TIMING): wall-clock stamps per block, slot 0..7
 #ifdef PP_TIMING
 __device__ unsigned long long pp_dbg_times[8 * 8192];

@@ -29,35 +29,11 @@
 
 namespace {
 
-// P[plane][k][step][out][16]: 16-bit pieces of w_t[i = 16*step + j][k][out] (times the
-// tensor's power-of-two scale for a ranged scheme).  One thread per (k, step, out): 16
-// reads coalesced over `out`, two 16-byte stores per plane.  ws = header | P.
 template <class SC>
 __global__ __launch_bounds__(256) void pp_split_pack_w_kernel(const float* __restrict__ wt,
                                                               void* __restrict__ ws, int I, int K,
                                                               int O, int nstep) {
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  const long per_plane = (long)K * nstep * O;  // in (k, step, out) slots of 32 bytes
-  if (id >= per_plane) return;
-  float scale = 1.0f, inv;
-  if constexpr (SC::kRanged) h2_scale(absmax_of_parts(ws), scale, inv);
-  u32x4* P = reinterpret_cast<u32x4*>(static_cast<char*>(ws) + kWsHeader);
-  const int o = (int)(id % O);
-  const int s = (int)((id / O) % nstep);
-  const int k = (int)(id / ((long)O * nstep));
-  float v[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int i = 16 * s + j;
-    v[j] = i < I ? wt[((size_t)i * K + k) * O + o] * scale : 0.0f;
-  }
-  u32x4 lo[SC::PL], hi[SC::PL];
-  split16<SC>(v, lo, hi);
-#pragma unroll
-  for (int p = 0; p < SC::PL; ++p) {
-    P[(p * per_plane + id) * 2] = lo[p];
-    P[(p * per_plane + id) * 2 + 1] = hi[p];
-  }
+  pack_w_body<SC>((long)blockIdx.x * 256 + threadIdx.x, wt, ws, I, K, O, nstep);
 }
 
 // plain fp32 recomputation of a tile (rows b0..b0+rows, outs o_lo..o_hi) by the whole
@@ -424,6 +400,29 @@ hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* 
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh) {
   return kWsHeader + (size_t)2 * sh.K * nstep_of(sh) * sh.O * 32;
 }
-void pp_launch_pack_w_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st) {
-  pack_w_split<SchemeH2>(wt, ws, sh, true, st);
+namespace {
+// both fp16x2 weight layouts in one launch: blocks [0, nblk_p) write P, the rest write Q
+__global__ __launch_bounds__(256) void pp_h2_pack_both_kernel(const float* __restrict__ wt,
+                                                              void* __restrict__ ws, unsigned q_off,
+                                                              int nblk_p, int I, int K, int O,
+                                                              int nstep, int nso, int Ipad) {
+  if ((int)blockIdx.x < nblk_p)
+    pack_w_body<SchemeH2>((long)blockIdx.x * 256 + threadIdx.x, wt, ws, I, K, O, nstep);
+  else
+    pack_wo_body<SchemeH2>((long)(blockIdx.x - nblk_p) * 256 + threadIdx.x, wt, ws, q_off, I, K, O,
+                           nso, Ipad);
+}
+}  // namespace
+
+// header (absmax) | P | Q: what pp_pack_weights_f32 writes
+void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st) {
+  const int nstep = nstep_of(sh);
+  const int nso = ((sh.O + 31) / 32) * 2, Ipad = ((sh.I + 31) / 32) * 32;  // as pp_bf3_bwdx.hip
+  hipLaunchKernelGGL(pp_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, wt,
+                     (long)sh.I * sh.K * sh.O, static_cast<unsigned*>(ws));
+  const int nblk_p = (int)(((long)sh.K * nstep * sh.O + 255) / 256);
+  const int nblk_q = (int)(((long)nso * sh.K * Ipad + 255) / 256);
+  hipLaunchKernelGGL(pp_h2_pack_both_kernel, dim3(nblk_p + nblk_q), dim3(256), 0, st, wt, ws,
+                     (unsigned)pp_h2_fwd_packed_bytes(sh), nblk_p, sh.I, sh.K, sh.O, nstep, nso,
+                     Ipad);
 }

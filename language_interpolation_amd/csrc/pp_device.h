@@ -95,6 +95,26 @@ __device__ __forceinline__ void pp_lagrange_d(float xi, const BasisTab& tab, flo
   }
 }
 
+// dl_j/dxi only (the dense backward-input epilogues need no l_j): closed forms for the
+// common low orders, the general recurrence otherwise.
+template <int N>
+__device__ __forceinline__ void pp_lagrange_dl(float xi, const BasisTab& tab, float (&dl)[N]) {
+  if constexpr (N == 1) {
+    dl[0] = 0.0f;
+  } else if constexpr (N == 2) {
+    dl[0] = tab.invden[0];
+    dl[1] = tab.invden[1];
+  } else if constexpr (N == 3) {
+    const float d0 = xi - tab.X[0], d1 = xi - tab.X[1], d2 = xi - tab.X[2];
+    dl[0] = (d1 + d2) * tab.invden[0];
+    dl[1] = (d0 + d2) * tab.invden[1];
+    dl[2] = (d0 + d1) * tab.invden[2];
+  } else {
+    float l[N];
+    pp_lagrange_d<N>(xi, tab, l, dl);
+  }
+}
+
 // Small fixed-width vector of floats with aligned global load/store.
 template <int V>
 struct PPVec;

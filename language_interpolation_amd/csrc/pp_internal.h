@@ -64,10 +64,8 @@ hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* 
                             const PPShape& sh, const BasisTab& tab, bool prepacked,
                             hipStream_t st);
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh);
-void pp_launch_pack_w_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st);
+void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st);
 size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh);
-void pp_launch_pack_wo_h2(const float* wt, void* ws, size_t q_off, const PPShape& sh,
-                          hipStream_t st);
 bool pp_bf3_bwd_x_supported(const PPShape& sh);
 size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,

@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(g, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
   for (int it = 0; it < 3; ++it) {
-    hipError_t e = (getenv("H2") ? pp_launch_bwd_x_h2(x, g, w, gx, ws, sh, tab, nullptr) : pp_launch_bwd_x_bf3(x, g, w, gx, ws, sh, tab, nullptr));
+    hipError_t e = (getenv("H2") ? pp_launch_bwd_x_h2(x, g, w, gx, ws, sh, tab, false, 256, nullptr) : pp_launch_bwd_x_bf3(x, g, w, gx, ws, sh, tab, nullptr));
     if (e != hipSuccess) { printf("launch failed %d\n", (int)e); return 1; }
   }
   (void)hipDeviceSynchronize();
