@@ -1,0 +1,347 @@
+"""Minimal training harness around the HIP layer.
+
+What the reference does with Lightning + Hydra
+(/root/reference/language_interpolation/networks.py:121-132 ClassificationMixin,
+:159-223 PredictionNetMixin, :750-954 select_network, :957-967 ASCIIPredictionNet;
+examples/high_order_interpolation.py) reduced to what feeds the hot path:
+
+* ``load_config``     reads the reference's yaml keys (``net.*``, ``optimizer.*``,
+                      ``batch_size``, ``data.max_features`` ...), ``defaults:`` groups and
+                      ``${a.b}`` interpolation, with PyYAML only;
+* ``select_network``  ``net.model_type`` ``high_order`` and ``high_order_input``;
+* ``ASCIIPredictionNet``  cross-entropy + accuracy = mean(argmax == y), optimizers
+                      ``adam`` / ``lion`` / ``sparse_lion``;
+* ``CharWindows``     text -> uint8 buffer ON THE DEVICE -> windows gathered on the GPU,
+                      ``x = (c - 64 + 0.5)/64`` (single_text_dataset.py:15-16, :102-123
+                      builds the same windows as Python lists);
+* ``fit``             the loop, one process per GPU (gradients summed by
+                      ``parallel.GradAllReducer`` when torch.distributed is initialised).
+
+Everything outside that (checkpoints, text generation, Gutenberg download, schedulers'
+plateau logic beyond lr decay) is the reference's control plane and stays out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import time
+from types import SimpleNamespace
+from typing import Any, Dict, Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from .layers import (LazyLayerNormLastDim, MaxAbsNormalizationLast, MaxCenterNormalizationLast,
+                     high_order_fc_layers)
+from .networks import HighOrderMLP, LowOrderMLP
+
+
+# ---------------------------------------------------------------------------
+# configuration (the reference's yaml files, no Hydra)
+# ---------------------------------------------------------------------------
+class Config(SimpleNamespace):
+    """Attribute access + ``get`` like the DictConfig the reference passes around."""
+
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+    def to_dict(self):
+        return {k: v.to_dict() if isinstance(v, Config) else v for k, v in vars(self).items()}
+
+
+def _wrap(obj):
+    if isinstance(obj, dict):
+        return Config(**{k: _wrap(v) for k, v in obj.items()})
+    return obj
+
+
+_INTERP = re.compile(r"\$\{([A-Za-z0-9_.]+)\}")
+# PyYAML (YAML 1.1) reads `1e-5` as a string; the reference's optimizer files use that form
+_FLOAT = re.compile(r"[-+]?(\d+\.?\d*|\.\d+)[eE][-+]?\d+")
+
+
+def _resolve(tree: Dict[str, Any]) -> Dict[str, Any]:
+    """``${net.features}``-style references, resolved against the root (a few passes)."""
+
+    def lookup(path):
+        node = tree
+        for part in path.split("."):
+            node = node[part]
+        return node
+
+    def visit(node):
+        if isinstance(node, dict):
+            return {k: visit(v) for k, v in node.items()}
+        if isinstance(node, list):
+            return [visit(v) for v in node]
+        if isinstance(node, str):
+            if _FLOAT.fullmatch(node):
+                return float(node)
+            m = _INTERP.fullmatch(node)
+            if m:
+                return lookup(m.group(1))
+            return _INTERP.sub(lambda mm: str(lookup(mm.group(1))), node)
+        return node
+
+    for _ in range(4):
+        tree = visit(tree)
+    return tree
+
+
+def _set_path(tree, dotted, value):
+    node = tree
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        node = node.setdefault(part, {})
+    node[parts[-1]] = value
+
+
+def load_config(path_or_dict, overrides: Iterable[str] = ()) -> Config:
+    """A reference-style config: a root yaml whose ``defaults: [{group: name}, ...]`` pull
+    ``<dir>/<group>/<name>.yaml`` under key ``group``; ``overrides`` are ``a.b=value``
+    strings (``net=small`` switches a group) as on the reference's command line."""
+    import yaml
+
+    overrides = list(overrides)
+    if isinstance(path_or_dict, dict):
+        tree = json.loads(json.dumps(path_or_dict))
+    else:
+        root_dir = os.path.dirname(os.path.abspath(path_or_dict))
+        with open(path_or_dict) as f:
+            tree = yaml.safe_load(f) or {}
+        groups = {}
+        for entry in tree.pop("defaults", []) or []:
+            if isinstance(entry, dict):
+                groups.update({k: v for k, v in entry.items() if not k.startswith("override")})
+        for ov in list(overrides):
+            k, _, v = ov.partition("=")
+            if k in groups and "." not in k:
+                groups[k] = v
+                overrides.remove(ov)
+        for group, name in groups.items():
+            with open(os.path.join(root_dir, group, f"{name}.yaml")) as f:
+                sub = yaml.safe_load(f) or {}
+            merged = dict(sub)
+            merged.update(tree.get(group, {}) or {})
+            tree[group] = merged
+    for ov in overrides:
+        k, _, v = ov.partition("=")
+        _set_path(tree, k, yaml.safe_load(v))
+    return _wrap(_resolve(tree))
+
+
+# ---------------------------------------------------------------------------
+# network selection (networks.py:46-69, :750-954 of the reference)
+# ---------------------------------------------------------------------------
+class _NoOpNormalizer(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def select_normalization(normalizer: str):
+    table = {"maxabs": MaxAbsNormalizationLast, "maxcenter": MaxCenterNormalizationLast,
+             "layer": LazyLayerNormLastDim, "none": _NoOpNormalizer}
+    if normalizer not in table:
+        raise ValueError(f"Normalization {normalizer} not recognized")
+    return table[normalizer]
+
+
+def select_network(cfg: Config, device=None) -> nn.Module:
+    net = cfg.net
+    device = device or cfg.get("accelerator", "cuda")
+    normalization = select_normalization(net.normalize)
+    if net.model_type == "high_order":
+        # (n_hidden is passed n_in, as the reference does: networks.py:871)
+        return HighOrderMLP(
+            layer_type=net.layer_type, n=net.n, n_in=net.n_in, n_hidden=net.n_in,
+            n_out=net.get("n_out"), in_width=net.input.width, in_segments=net.input.segments,
+            out_width=net.output.width, out_segments=net.output.segments,
+            hidden_width=net.hidden.width, hidden_layers=net.hidden.layers,
+            hidden_segments=net.hidden.segments, normalization=normalization, device=device,
+            layer_type_in=net.input.get("layer_type"))
+    if net.model_type == "high_order_input":
+        layers = [high_order_fc_layers(layer_type=net.layer_type, n=net.n,
+                                       in_features=net.input.width,
+                                       out_features=net.hidden.width,
+                                       segments=net.input.segments, device=device),
+                  normalization(),
+                  LowOrderMLP(in_width=net.hidden.width, out_width=net.output.width,
+                              hidden_width=net.hidden.width, hidden_layers=net.hidden.layers - 1,
+                              non_linearity=nn.ReLU(), normalization=normalization,
+                              device=device)]
+        return nn.Sequential(*layers)
+    raise ValueError(f"model_type {net.model_type!r} is outside the hot path "
+                     "(supported: high_order, high_order_input)")
+
+
+# ---------------------------------------------------------------------------
+# optimizers the reference's configs name (lion_pytorch.Lion, high-order-layers-torch's
+# SparseLion: Lion that leaves entries with a zero gradient untouched)
+# ---------------------------------------------------------------------------
+class Lion(torch.optim.Optimizer):
+    """update = sign(b1*m + (1-b1)*g); p -= lr*(update + wd*p); m = b2*m + (1-b2)*g."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0, sparse=False):
+        super().__init__(params, dict(lr=lr, betas=betas, weight_decay=weight_decay))
+        self.sparse = sparse
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            lr, (b1, b2), wd = group["lr"], group["betas"], group["weight_decay"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                m = st["exp_avg"]
+                update = (m * b1).add_(g, alpha=1 - b1).sign_()
+                new_m = (m * b2).add_(g, alpha=1 - b2)
+                if self.sparse:  # weights no sample touched keep value and momentum
+                    touched = g != 0
+                    update = update * touched
+                    new_m = torch.where(touched, new_m, m)
+                if wd:
+                    p.mul_(1 - lr * wd)
+                p.add_(update, alpha=-lr)
+                m.copy_(new_m)
+        return loss
+
+
+class ASCIIPredictionNet(nn.Module):
+    """`ASCIIPredictionNet` without Lightning: ``self.model`` + cross entropy."""
+
+    def __init__(self, cfg: Config, device=None):
+        super().__init__()
+        self.cfg = cfg
+        self.model = select_network(cfg, device)
+        self.loss = nn.CrossEntropyLoss()
+
+    def forward(self, x):
+        return self.model(x)
+
+    def eval_step(self, batch):
+        x, y = batch[0], batch[1]
+        y_hat = self(x)
+        loss = self.loss(y_hat, y.flatten())
+        accuracy = (torch.argmax(y_hat, dim=1) == y.flatten()).float().mean()
+        return loss, accuracy
+
+    def configure_optimizers(self):
+        opt = self.cfg.optimizer
+        if opt.name == "adam":
+            return torch.optim.Adam(self.parameters(), lr=opt.lr)
+        if opt.name == "lion":
+            return Lion(self.parameters(), lr=opt.lr, weight_decay=0.0)
+        if opt.name == "sparse_lion":
+            return Lion(self.parameters(), lr=opt.lr, weight_decay=0.0, sparse=True)
+        raise ValueError(f"Optimizer {opt.name} not recognized")
+
+
+# ---------------------------------------------------------------------------
+# data: character windows gathered on the device
+# ---------------------------------------------------------------------------
+def ascii_to_float(c: torch.Tensor) -> torch.Tensor:
+    return (c - 64 + 0.5) / 64
+
+
+class CharWindows:
+    """All windows of ``features`` characters + the next one as target, held as ONE uint8
+    buffer on the device; a batch is an index gather (what generate_dataset builds as
+    Python lists of ord() values, single_text_dataset.py:102-123)."""
+
+    def __init__(self, text, features: int, device="cuda"):
+        if isinstance(text, str):
+            text = text.encode("ascii", "ignore")
+        self.features = features
+        self.buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(device)
+        self.n = self.buf.numel() - (features + 1)
+        if self.n <= 0:
+            raise ValueError("text shorter than one window")
+        self._ar = torch.arange(features, device=self.buf.device)
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, idx: torch.Tensor):
+        idx = idx.to(self.buf.device)
+        win = self.buf[idx.unsqueeze(1) + self._ar]
+        x = ascii_to_float(win.float())
+        y = self.buf[idx + self.features].long().unsqueeze(1)
+        return x, y, idx
+
+    def sample(self, batch_size: int, generator=None):
+        idx = torch.randint(0, self.n, (batch_size,), generator=generator)
+        return self.batch(idx)
+
+
+def synthetic_text(nchar: int, seed: int = 0) -> bytes:
+    """Printable-ASCII text with word structure (no dataset ships with the build)."""
+    g = torch.Generator().manual_seed(seed)
+    words = [bytes(torch.randint(97, 123, (int(n),), generator=g).tolist())
+             for n in torch.randint(2, 9, (200,), generator=g)]
+    out = bytearray()
+    while len(out) < nchar:
+        out += words[int(torch.randint(0, len(words), (1,), generator=g))] + b" "
+    return bytes(out[:nchar])
+
+
+# ---------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------
+def fit(module: ASCIIPredictionNet, data: CharWindows, steps: int, batch_size: int,
+        seed: int = 0, log_every: int = 0):
+    """`steps` optimizer steps; returns the list of (loss, accuracy) per step."""
+    import torch.distributed as dist
+
+    from .parallel import GradAllReducer, broadcast_parameters
+
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    gen = torch.Generator().manual_seed(seed + rank)
+    optimizer = module.configure_optimizers()
+    reducer = None
+    if distributed:
+        broadcast_parameters(module)
+        reducer = GradAllReducer(module.parameters())
+    history = []
+    t0 = time.perf_counter()
+    for step in range(steps):
+        batch = data.sample(batch_size, gen)
+        optimizer.zero_grad(set_to_none=True)
+        loss, acc = module.eval_step(batch)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        optimizer.step()
+        history.append((loss.detach(), acc.detach()))
+        if log_every and rank == 0 and (step + 1) % log_every == 0:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"step {step + 1}: loss {loss.item():.4f} acc {acc.item():.3f} "
+                  f"{(step + 1) * batch_size / dt:.0f} chars/s per GPU", flush=True)
+    return [(float(l), float(a)) for l, a in history]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("--config", required=True, help="root yaml in the reference's layout")
+    ap.add_argument("--text", default=None, help="ASCII text file (default: synthetic text)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("overrides", nargs="*", help="a.b=value, or group=name")
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config, args.overrides)
+    text = open(args.text, "rb").read() if args.text else synthetic_text(1 << 20)
+    module = ASCIIPredictionNet(cfg, device="cuda")
+    data = CharWindows(text, cfg.net.features, device="cuda")
+    hist = fit(module, data, args.steps, cfg.batch_size, log_every=max(1, args.steps // 10))
+    print(json.dumps({"final_loss": hist[-1][0], "final_acc": hist[-1][1], "steps": len(hist)}))
+
+
+if __name__ == "__main__":
+    main()

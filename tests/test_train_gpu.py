@@ -1,0 +1,90 @@
+"""Training harness on the GPU: a few optimizer steps of the HIP network against the same
+steps of the CPU oracle network (same init, same batches), and learning on a small text."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "high_order_interpolation.yaml")
+
+
+def _oracle_twin(module, cfg):
+    from oracle import pp_oracle as po
+    net = cfg.net
+    ora = po.OracleHighOrderMLP(
+        layer_type=net.layer_type, n=net.n, n_in=net.n_in, n_hidden=net.n_in,
+        n_out=net.get("n_out"), in_width=net.input.width, in_segments=net.input.segments,
+        out_width=net.output.width, out_segments=net.output.segments,
+        hidden_width=net.hidden.width, hidden_layers=net.hidden.layers,
+        hidden_segments=net.hidden.segments, normalization=po.OracleLazyLayerNormLastDim,
+        layer_type_in=net.input.get("layer_type")).double()
+    with torch.no_grad():
+        for a, b in zip(ora.parameters(), module.model.parameters()):
+            a.copy_(b.detach().cpu().double())
+    return ora
+
+
+@pytest.mark.parametrize("overrides", [
+    ["net=small", "optimizer=adam", "optimizer.lr=1e-3"],
+    ["net=baseline_small_250", "net.hidden.width=40", "net.hidden.layers=1", "optimizer=adam",
+     "optimizer.lr=1e-3"],
+])
+def test_training_steps_match_oracle(overrides):
+    from language_interpolation_amd import train as T
+    torch.manual_seed(0)
+    cfg = T.load_config(CFG, overrides + ["batch_size=96"])
+    module = T.ASCIIPredictionNet(cfg, device="cuda")
+    ora = _oracle_twin(module, cfg)
+    text = T.synthetic_text(4000, seed=3)
+    data = T.CharWindows(text, cfg.net.features, device="cuda")
+    opt = module.configure_optimizers()
+    opt_o = torch.optim.Adam(ora.parameters(), lr=cfg.optimizer.lr)
+    ce = torch.nn.CrossEntropyLoss()
+    gen = torch.Generator().manual_seed(5)
+    for step in range(4):
+        x, y, _ = data.sample(cfg.batch_size, gen)
+        opt.zero_grad()
+        loss, acc = module.eval_step((x, y))
+        loss.backward()
+        opt.step()
+        opt_o.zero_grad()
+        lo = ce(ora(x.cpu().double()), y.cpu().flatten())
+        lo.backward()
+        opt_o.step()
+        assert abs(loss.item() - lo.item()) <= 2e-4 * max(1.0, abs(lo.item())), (step, loss.item(), lo.item())
+        assert 0.0 <= acc.item() <= 1.0
+    # after four Adam steps the weights still agree (Adam's sign-like first steps amplify
+    # gradient noise, hence the looser bar)
+    for a, b in zip(ora.parameters(), module.model.parameters()):
+        assert (a.detach().float() - b.detach().cpu()).abs().max().item() <= 2e-4
+
+
+def test_fit_learns_a_repeating_text():
+    from language_interpolation_amd import train as T
+    torch.manual_seed(1)
+    cfg = T.load_config(CFG, ["net=baseline_small_250", "net.hidden.width=64",
+                              "net.hidden.layers=1", "optimizer=adam", "optimizer.lr=2e-3",
+                              "batch_size=512"])
+    module = T.ASCIIPredictionNet(cfg, device="cuda")
+    data = T.CharWindows(b"the cat sat on the mat and the dog sat on the log. " * 40,
+                         cfg.net.features, device="cuda")
+    hist = T.fit(module, data, steps=150, batch_size=cfg.batch_size, seed=2)
+    first = sum(l for l, _ in hist[:5]) / 5
+    last = sum(l for l, _ in hist[-5:]) / 5
+    assert last < 0.5 * first, (first, last)
+    assert hist[-1][1] > 0.6
+
+
+def test_high_order_input_network_and_sparse_lion_step():
+    from language_interpolation_amd import train as T
+    torch.manual_seed(2)
+    cfg = T.load_config(CFG, ["net=large_standard", "net.hidden.width=64", "batch_size=300"])
+    module = T.ASCIIPredictionNet(cfg, device="cuda")
+    data = T.CharWindows(T.synthetic_text(5000), cfg.net.features, device="cuda")
+    hist = T.fit(module, data, steps=3, batch_size=cfg.batch_size)
+    assert len(hist) == 3 and all(l == l for l, _ in hist)
+    w = module.model[0].w
+    assert w.grad is not None and (w.grad == 0).any()   # untouched segments: sparse gradient
