@@ -128,6 +128,55 @@ def roofline_for_hidden_layer(B, dev):
     }
 
 
+def step_bytes(B):
+    """Algorithmic HBM bytes of one fwd+bwd step of the network (every operand
+    touched once per pass): 4*(3*B*I + 2*B*O + 3*W) per interior layer, 4*(2*B*I + 2*B*O + 2*W)
+    for the first layer; LayerNorm passes not counted."""
+    layers = [(16, 250, 129, True)] + [(250, 250, 5, False)] * 3 + [(250, 128, 5, False)]
+    total = 0
+    for I, O, K, first in layers:
+        W = I * K * O
+        total += 4 * ((2 * B * I + 2 * B * O + 2 * W) if first else (3 * B * I + 2 * B * O + 3 * W))
+    return total
+
+
+def train_chars_per_s(net, dev, B, steps, world, reducer):
+    """The other half of BASELINE's metric: optimizer steps of the same network on character
+    windows gathered on the device (cross entropy, Adam), eager launches."""
+    from language_interpolation_amd.train import CharWindows, synthetic_text
+
+    data = CharWindows(synthetic_text(1 << 20, seed=7), 16, device=dev)
+    gen = torch.Generator().manual_seed(11)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    ce = torch.nn.CrossEntropyLoss()
+
+    def one():
+        xb, yb, _ = data.sample(B, gen)
+        opt.zero_grad(set_to_none=True)
+        ce(net(xb), yb.flatten()).backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return world * B * steps / dt
+
+
 def cpu_baseline(rows, steps=2):
     """The CPU oracle in the reference formulation (gather [B,I,O,n] + einsum +
     autograd), same network, on this box's host cores."""
@@ -166,6 +215,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--train-steps", type=int, default=20,
+                    help="optimizer steps for the extra train chars/s figure (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,6 +294,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    train_cps = None
+    if args.train_steps > 0:
+        graph = graph  # (the captured graph keeps its own buffers; training runs eager)
+        train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
@@ -268,6 +324,13 @@ def main():
                 "grad_allreduce": "rccl, per-parameter, overlapped with backward" if world > 1 else None,
             },
         }
+        if train_cps is not None:
+            out["train_chars_per_s"] = round(train_cps, 1)  # cross entropy + Adam, eager
+        hb = step_bytes(B)
+        out["hbm_roofline"] = {"algorithmic_bytes_per_step": hb,
+                               "achieved_GBs": round(hb / (dt / args.steps) * 1e-9, 1),
+                               "frac_of_8TBs": round(hb / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4),
+                               "note": "segments=2 layers are MFMA-bound (SURVEY 8d): structurally low"}
         if world == 1:
             out["roofline"] = roofline_for_hidden_layer(B, dev)
             if not args.no_cpu_baseline:
