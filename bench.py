@@ -118,9 +118,17 @@ def roofline_for_hidden_layer(B, dev):
     name = max(times, key=times.get)
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)
     achieved = flops / times[name] * 1e-12
+    # HBM-side bytes per launch of the weight-gradient entry point: measured offline with
+    # rocprofv3 --pmc (separate passes; profiles/r01_e_traffic.json says how), valid for the
+    # shape and method it was taken on
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
+    if B == 16384 and methods[2] == 5 and name == wname and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["traffic_bytes"]
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
         "kernel": name, "layer": "continuous n=3 250->250 S=2 (cfg2 hidden)", "rows": B,
         "algorithmic_flops_per_launch": flops,
         "launch_us": {k: round(v * 1e6, 2) for k, v in times.items()},

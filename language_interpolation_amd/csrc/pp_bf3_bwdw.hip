@@ -136,8 +136,12 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int r = lane & 31, h = lane >> 5;
-  const int i0 = blockIdx.x * 32;
-  const int chunk = blockIdx.y;
+  // grid = (row chunks, input tiles, out tiles): workgroups go round-robin over the 8 XCDs
+  // by linear id, so the input-tile blocks of one row chunk share an XCD and its L2 serves
+  // all but the first read of the chunk's gy fragments (with the input tile in x they sat on
+  // 8 different XCDs and each fetched the chunk through the fabric: 171 MB vs 34 MB)
+  const int i0 = blockIdx.y * 32;
+  const int chunk = blockIdx.x;
   const int o0 = (blockIdx.z * 4 + wv) * (32 * NT);
   const int cbeg = chunk * rows_per_chunk;  // multiple of 16
   const int cend = min(sh.B, cbeg + rows_per_chunk);
@@ -344,7 +348,7 @@ hipError_t launch_bwd_w_bf3(const float* x, const float* gy, const void* ws, flo
       once = true;
     }
   }
-  dim3 grid((sh.I + 31) / 32, p.nchunk, p.ocols);
+  dim3 grid(p.nchunk, (sh.I + 31) / 32, p.ocols);
   const char* base = static_cast<const char*>(ws);
   hipLaunchKernelGGL((pp_bwd_w_bf3_kernel<SC, N, K, NT>), grid, dim3(256), lds, st, x, gy,
                      reinterpret_cast<const float2*>(base), (const void*)(base + p.sc_bytes), out,
