@@ -237,6 +237,27 @@ def test_fp16x2_backward_weight_row_blocks_and_range():
         assert rel_err(gg[:, sl], rr[:, sl]) <= TOL, sl
 
 
+# every (n, K) instantiation of the matrix-core kernels, in the large-batch variants
+# (64-row tiles need B >= 8192; O <= 128 selects the 32-out wave tiles)
+_COMBOS = [(1, 1, True), (1, 2, True), (1, 4, True), (1, 8, True), (2, 1, True), (2, 1, False),
+           (2, 2, True), (2, 2, False), (2, 4, True), (2, 4, False), (3, 1, True), (3, 2, False),
+           (3, 2, True), (4, 1, True), (4, 2, False), (4, 2, True), (5, 1, True), (6, 1, True),
+           (7, 1, True), (8, 1, True)]
+
+
+@pytest.mark.parametrize("combo", _COMBOS, ids=lambda c: f"n{c[0]}-S{c[1]}-{'d' if c[2] else 'c'}")
+@pytest.mark.parametrize("O", [100, 160])
+def test_fp16x2_all_instantiations_large_batch(combo, O):
+    n, S, disc = combo
+    if not disc and n < 2:
+        pytest.skip("continuous layers need n >= 2")
+    B, I = 8200, 70
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=20 + n + S)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc, "fp16x2", "fp16x2", "fp16x2"), ref, "fp16x2 large")
+    check(hip_all(x, w, gy, n, S, disc), ref, "auto large")   # pre-split weights + auto
+
+
 def test_prepacked_weights_match_per_call_packing():
     """pp_pack_weights_f32 + PP_WS_PREPACKED give bit-identical results to the per-call path."""
     PF = _pf()
