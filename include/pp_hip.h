@@ -164,6 +164,19 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
 int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream);
 int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* stream);
 
+/* Forward of a dense-regime layer with the FOLLOWING non-affine LayerNorm fused into the
+ * kernel's epilogue (the layer -> LazyLayerNormLastDim pairs of HighOrderMLP,
+ * networks.py:866-882 with normalization=LazyLayerNormLastDim): y = LN(layer(x)), rstd[B] as
+ * pp_layer_norm_fwd_f32 writes it (pp_layer_norm_bwd_f32 is the matching backward).  Runs the
+ * fp16x2 kernel on weights pre-split by pp_pack_weights_f32 (`packed`).
+ * pp_forward_layer_norm_supported: 1 when this shape has the fused kernel (dense regime,
+ * O <= 256) and it is what PP_METHOD_AUTO would run. */
+int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous);
+int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float* rstd,
+                              void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
+                              int discontinuous, float length, const float* nodes, float out_scale,
+                              float eps, void* stream);
+
 /* Non-affine LayerNorm over the last dim (what LazyLayerNormLastDim computes:
  * /root/reference/language_interpolation/networks.py:72-91, eps 1e-5, weight/bias
  * frozen at 1/0).  y[B,D] = (x - mean)/sqrt(var + eps); rstd[B] is saved for the

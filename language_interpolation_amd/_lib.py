@@ -61,6 +61,12 @@ SIGNATURES = {
         [_P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float,
          c_int, _P],
     ),
+    "pp_forward_layer_norm_supported": (c_int, [c_int] * 6),
+    "pp_forward_layer_norm_f32": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
+         c_float, c_float, _P],
+    ),
     "pp_layer_norm_fwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "pp_layer_norm_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "pp_max_abs_norm_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_float, _P]),

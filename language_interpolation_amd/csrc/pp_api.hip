@@ -157,7 +157,7 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
   if (method == (PP_FWD_FP16X2 | PP_WS_PREPACKED)) {
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
-    return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, true,
+    return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, true, nullptr, 0.0f,
                                    (hipStream_t)stream));
   }
   if (method == PP_METHOD_AUTO) {
@@ -175,7 +175,8 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_fwd_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
     if (method == PP_FWD_FP16X2)
-      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, false, st));
+      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, false, nullptr, 0.0f,
+                                     st));
     return hip_rc(pp_launch_fwd_bf3(x, w_t, y, seg_out, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;
@@ -323,6 +324,30 @@ static int norm_args_ok(int B, int D) {
   if (B < 1 || D < 1 || D > 1024) return PP_ERR_SHAPE;
   if ((long)B * D >= (1L << 31)) return PP_ERR_RANGE;
   return PP_OK;
+}
+
+int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float* rstd,
+                              void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
+                              int discontinuous, float length, const float* nodes, float out_scale,
+                              float eps, void* stream) {
+  if (!x || !w_t || !y || !rstd || !packed) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(w_t) || !aligned16(y) || !aligned16(packed)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (!pp_h2_fwd_ln_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
+  if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_fwd_h2(x, w_t, y, nullptr, packed, sh, tab, true, rstd, eps,
+                                 (hipStream_t)stream));
+}
+
+int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous) {
+  PPShape sh;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  return pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && dense_preferred(sh) &&
+         sh.B >= 256;
 }
 
 int pp_layer_norm_fwd_f32(const float* x, float* y, float* rstd, int B, int D, float eps,

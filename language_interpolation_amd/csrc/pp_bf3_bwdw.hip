@@ -276,7 +276,11 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
     if (t + 5 < nst) stepfn(t + 5, std::integral_constant<int, 5>{});
   }
   float* dst = out + (size_t)chunk * sh.I * K * sh.O;
-  if (o0 < sh.O) {  // wave-uniform: else this wave ran on clamped columns
+  // a basis value outside fp16's range anywhere in this tile: the tile is redone in fp32
+  // below instead of being stored (decided before any store, so the two never overlap)
+  bool bad = false;
+  if constexpr (SC::kRanged) bad = __syncthreads_or(!(lmax <= kH2Limit));
+  if (!bad && o0 < sh.O) {  // wave-uniform: else this wave ran on clamped columns
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = o0 + nt * 32 + r;
@@ -293,11 +297,9 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
       }
     }
   }
-  if constexpr (SC::kRanged) {
-    if (__syncthreads_or(!(lmax <= kH2Limit)))
-      bwd_w_tile_fp32<N, K>(x, gy, dst, sh, tab, dc, i0, blockIdx.z * 128 * NT,
-                            min(sh.O, (int)(blockIdx.z + 1) * 128 * NT), cbeg, cend, scale);
-  }
+  if (bad)
+    bwd_w_tile_fp32<N, K>(x, gy, dst, sh, tab, dc, i0, blockIdx.z * 128 * NT,
+                          min(sh.O, (int)(blockIdx.z + 1) * 128 * NT), cbeg, cend, scale);
 }
 
 }  // namespace

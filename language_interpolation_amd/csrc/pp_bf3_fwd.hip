@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
                                                              const void* __restrict__ ws,
                                                              float* __restrict__ y, PPShape sh,
                                                              BasisTab tab, DenseCoord3 dc,
-                                                             int nstep) {
+                                                             int nstep, float* __restrict__ rstd_out,
+                                                             float ln_eps) {
+  // rstd_out != nullptr: y is the non-affine LayerNorm of the layer's output over the row
+  // (LazyLayerNormLastDim fused into the epilogue) and rstd_out[B] its 1/std.
   // block = G groups of 4 waves.  A group = 4 column tiles (32*NT outs each) x one tile
   // of 32*RM rows; every W fragment a wave loads feeds RM row tiles.  With G = 2 the two
   // groups take alternate 16-input steps of the SAME output tile (split-k inside the
@@ -191,18 +194,17 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   PP_TICK(1)
-  // LATE = false: evaluate the next step's basis, then run this step's MFMAs; LATE = true:
-  // the other way round.  The two groups of a block use opposite orders, so on every SIMD
-  // one wave issues vector work while the other issues matrix work.
-  auto stepfn = [&](int t, auto par, auto late) {
+  // (An earlier version ran the two groups in opposite orders -- basis first vs MFMAs first
+  // -- to interleave vector and matrix work on a SIMD; it bought ~3 % and gave intermittently
+  // wrong rows in one instantiation (N = K = 7, three steps per group), so both groups use
+  // the same order.)
+  auto stepfn = [&](int t, auto par) {
     constexpr int P0 = decltype(par)::value;
-    constexpr bool LATE = decltype(late)::value;
     const int buf = t & 1;
     const int s = t * G + g;
     xload(s + 2 * G, xn);
     aload(buf, 0, A[P0 & 1]);
-    if (!LATE && t + 1 < T) produce(s + G, buf ^ 1, xv);
-    if (!LATE) __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < T) produce(s + G, buf ^ 1, xv);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int cur = (k + P0) & 1, nxt = cur ^ 1;
@@ -220,8 +222,6 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
         mm(A[cur], W[cur]);
       }
     }
-    if (LATE) __builtin_amdgcn_sched_barrier(0);
-    if (LATE && t + 1 < T) produce(s + G, buf ^ 1, xv);
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
       xv[rm][0] = xn[rm][0];
@@ -229,52 +229,40 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
     }
     __syncthreads();
   };
-  auto run = [&](auto late) {
-    for (int t = 0; t < T; t += 2) {
-      stepfn(t, std::integral_constant<int, 0>{}, late);
-      if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{}, late);
-    }
-  };
-  if (g == 0) run(std::false_type{});
-  else run(std::true_type{});
+  for (int t = 0; t < T; t += 2) {
+    stepfn(t, std::integral_constant<int, 0>{});
+    if (t + 1 < T) stepfn(t + 1, std::integral_constant<int, (K & 1)>{});
+  }
   PP_TICK(2)
 
+  // a basis value outside fp16's range anywhere in this tile: the tile is redone in fp32
+  // below instead of being stored (decided before any store, so the two never overlap)
+  bool bad = false;
+  if constexpr (SC::kRanged) bad = __syncthreads_or(!(lmax <= kH2Limit));
   float oscale = sh.out_scale;
   if constexpr (SC::kRanged) {
     float sc, inv;
     h2_scale(absmax_of_parts(ws), sc, inv);
     oscale *= inv;
   }
-  // accumulator tiles of this wave: tix = rm*NT + nt
+  // accumulator tiles of this wave: tix = rm*NT + nt.  With two groups, group g finishes
+  // the tiles with tix % 2 == g (all of them in group 0 when there is only one) and hands
+  // the others to the partner wave (same cw, other group) through LDS (the basis buffers
+  // are free: the loop ended on a barrier).
   constexpr int NTILE = RM * NT;
-  auto store_tile = [&](auto tc, const float* part) {
-    constexpr int tix = decltype(tc)::value;
-    constexpr int rm = tix / NT, nt = tix % NT;
-    const int col = o0 + nt * 32 + r;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      float v = acc[rm][nt][q];
-      if (part) v += part[q * 64];
-      if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = v * oscale;
-    }
-  };
-  if constexpr (G == 1) {
-    static_for<NTILE>([&](auto tc) { store_tile(tc, nullptr); });
-  } else {
-    // group g finishes the tiles with tix % 2 == g (all of them in group 0 when there
-    // is only one) and hands the others to the partner wave (same cw, other group)
-    // through LDS (the basis buffers are free: the loop ended on a barrier)
-    constexpr int NX = NTILE > 1 ? NTILE / 2 : 1;  // tiles a wave hands over
-    float* red = reinterpret_cast<float*>(phiL);   // [g][cw][NX][16][64]
-    float* mine = red + ((g * 4 + cw) * NX * 16) * 64 + lane;
-    const float* theirs = red + (((g ^ 1) * 4 + cw) * NX * 16) * 64 + lane;
-    auto exchange = [&](auto gc) {
-      constexpr int GS = decltype(gc)::value;  // this wave's group
+  constexpr int NX = NTILE > 1 ? NTILE / 2 : 1;  // tiles a wave hands over
+  constexpr int kRedFloats = G == 2 ? 2 * 4 * NX * 16 * 64 : 0;
+  float* red = reinterpret_cast<float*>(phiL);   // [g][cw][NX][16][64]
+  float* statL = red + kRedFloats;               // LayerNorm: [4G waves][ROWS] | mean | rstd
+  auto finish = [&](auto gc) {
+    constexpr int GS = decltype(gc)::value;  // this wave's group
+    auto kept = [](int T) { return G == 1 || (NTILE == 1 ? GS == 0 : (T & 1) == GS); };
+    if constexpr (G == 2) {
+      float* mine = red + ((g * 4 + cw) * NX * 16) * 64 + lane;
+      const float* theirs = red + (((g ^ 1) * 4 + cw) * NX * 16) * 64 + lane;
       static_for<NTILE>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        constexpr bool keep = NTILE == 1 ? GS == 0 : (T & 1) == GS;
-        if constexpr (!keep) {
+        if constexpr (!kept(T)) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) mine[((T >> 1) * 16 + q) * 64] = acc[T / NT][T % NT][q];
         }
@@ -282,19 +270,112 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
       __syncthreads();
       static_for<NTILE>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        constexpr bool keep = NTILE == 1 ? GS == 0 : (T & 1) == GS;
-        if constexpr (keep) store_tile(tc, theirs + (T >> 1) * 16 * 64);
+        if constexpr (kept(T)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[T / NT][T % NT][q] += theirs[((T >> 1) * 16 + q) * 64];
+        }
       });
-    };
-    if (g == 0) exchange(std::integral_constant<int, 0>{});
-    else exchange(std::integral_constant<int, 1>{});
+    }
+    static_for<NTILE>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      if constexpr (kept(T)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[T / NT][T % NT][q] *= oscale;
+      }
+    });
+    if (rstd_out) {
+      // fused non-affine LayerNorm over the row (the block holds whole rows: grid.y == 1):
+      // two passes (mean, then centred second moment), partial row sums per wave in LDS
+      float* meanL = statL + 4 * G * ROWS;
+      float* rsL = meanL + ROWS;
+      auto row_pass = [&](bool centred) {
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rr = rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float mu = centred ? meanL[rr] : 0.0f;
+            float sacc = 0.0f;
+            static_for<NT>([&](auto nc) {
+              constexpr int nt = decltype(nc)::value;
+              if (kept(rm * NT + nt)) {  // (folds after unrolling)
+                const float d = acc[rm][nt][q] - mu;
+                if (o0 + nt * 32 + r < sh.O) sacc += centred ? d * d : d;
+              }
+            });
+#pragma unroll
+            for (int dd = 16; dd > 0; dd >>= 1) sacc += __shfl_xor(sacc, dd);
+            if (r == 0) statL[wv * ROWS + rr] = sacc;
+          }
+        __syncthreads();
+        if (threadIdx.x < ROWS) {
+          float tot = 0.0f;
+#pragma unroll
+          for (int w = 0; w < 4 * G; ++w) tot += statL[w * ROWS + threadIdx.x];
+          if (!centred) {
+            meanL[threadIdx.x] = tot / (float)sh.O;
+          } else {
+            const float rs = 1.0f / sqrtf(tot / (float)sh.O + ln_eps);
+            rsL[threadIdx.x] = rs;
+            if (b0 + (int)threadIdx.x < sh.B) rstd_out[b0 + threadIdx.x] = rs;
+          }
+        }
+        __syncthreads();
+      };
+      row_pass(false);
+      row_pass(true);
+      static_for<NTILE>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr (kept(T)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rr = (T / NT) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            acc[T / NT][T % NT][q] = (acc[T / NT][T % NT][q] - meanL[rr]) * rsL[rr];
+          }
+        }
+      });
+    }
+    static_for<NTILE>([&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      if constexpr (kept(T)) {
+        constexpr int rm = T / NT, nt = T % NT;
+        const int col = o0 + nt * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (col < sh.O && row < sh.B) y[(size_t)row * sh.O + col] = acc[rm][nt][q];
+        }
+      }
+    });
+  };
+  if (!bad) {  // block-uniform
+    if (G == 1 || g == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
   }
   PP_TICK(3)
   if constexpr (SC::kRanged) {
-    // a basis value outside fp16's range anywhere in this tile: redo the tile in fp32
-    if (__syncthreads_or(!(lmax <= kH2Limit)))
+    if (bad) {
       fwd_tile_fp32<N, K>(x, wt, y, sh, tab, dc, b0, ROWS, blockIdx.y * 128 * NT,
                           min(sh.O, (int)(blockIdx.y + 1) * 128 * NT));
+      if (rstd_out) {  // ... and normalise its rows in place: wave w takes rows w, w+4G, ...
+        __syncthreads();
+        for (int rr = wv; rr < ROWS && b0 + rr < sh.B; rr += 4 * G) {
+          float* yr = y + (size_t)(b0 + rr) * sh.O;
+          float sacc = 0.0f;
+          for (int c = lane; c < sh.O; c += 64) sacc += yr[c];
+#pragma unroll
+          for (int dd = 32; dd > 0; dd >>= 1) sacc += __shfl_xor(sacc, dd);
+          const float mu = sacc / (float)sh.O;
+          float vacc = 0.0f;
+          for (int c = lane; c < sh.O; c += 64) vacc += (yr[c] - mu) * (yr[c] - mu);
+#pragma unroll
+          for (int dd = 32; dd > 0; dd >>= 1) vacc += __shfl_xor(vacc, dd);
+          const float rs = 1.0f / sqrtf(vacc / (float)sh.O + ln_eps);
+          for (int c = lane; c < sh.O; c += 64) yr[c] = (yr[c] - mu) * rs;
+          if (lane == 0) rstd_out[b0 + rr] = rs;
+        }
+      }
+    }
   }
 }
 
@@ -303,9 +384,12 @@ int nstep_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 2; }
 
 template <class SC, int N, int K, int RM, int NT, int G>
 hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y, const PPShape& sh,
-                      const BasisTab& tab, const DenseCoord3& dc, int nstep, hipStream_t st) {
+                      const BasisTab& tab, const DenseCoord3& dc, int nstep, float* rstd,
+                      float ln_eps, hipStream_t st) {
   size_t lds = (size_t)G * 2 * SC::PL * K * 2 * 32 * RM * 16;
-  if (G == 2) lds = std::max(lds, (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4);
+  // epilogue: exchange area of the two groups + LayerNorm row statistics
+  const size_t red = G == 2 ? (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4 : 0;
+  lds = std::max(lds, red + (size_t)(4 * G + 2) * 32 * RM * 4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
     static bool once = false;  // per instantiation
@@ -317,8 +401,9 @@ hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y,
     }
   }
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 128 * NT - 1) / (128 * NT));
+  if (rstd && grid.y != 1) return hipErrorInvalidValue;  // the fused norm needs whole rows
   hipLaunchKernelGGL((pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>), grid, dim3(256 * G), lds, st, x, wt,
-                     ws, y, sh, tab, dc, nstep);
+                     ws, y, sh, tab, dc, nstep, rstd, ln_eps);
   return hipGetLastError();
 }
 
@@ -335,8 +420,8 @@ void pack_w_split(const float* wt, void* ws, const PPShape& sh, bool with_absmax
 
 template <class SC>
 hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                            const PPShape& sh, const BasisTab& tab, bool prepacked,
-                            hipStream_t st) {
+                            const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
+                            float ln_eps, hipStream_t st) {
   const int nstep = nstep_of(sh);
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
@@ -360,12 +445,12 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
     hipError_t e = hipErrorInvalidValue;                                                       \
     if constexpr (K_ <= 6) {                                                                   \
       if (rm == 2 && nt == 2)                                                                  \
-        e = launch_bf3<SC, N_, K_, 2, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, st);             \
+        e = launch_bf3<SC, N_, K_, 2, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st);             \
       else if (rm == 2)                                                                        \
-        e = launch_bf3<SC, N_, K_, 2, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, st);             \
+        e = launch_bf3<SC, N_, K_, 2, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st);             \
     }                                                                                          \
-    if (rm == 1 && nt == 2) e = launch_bf3<SC, N_, K_, 1, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, st); \
-    else if (rm == 1) e = launch_bf3<SC, N_, K_, 1, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, st); \
+    if (rm == 1 && nt == 2) e = launch_bf3<SC, N_, K_, 1, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st); \
+    else if (rm == 1) e = launch_bf3<SC, N_, K_, 1, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st); \
     if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                     \
     return e;                                                                                  \
   }
@@ -387,14 +472,17 @@ size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
 
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                              const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, false, st);
+  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, false, nullptr, 0.0f, st);
 }
 
 hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                            const PPShape& sh, const BasisTab& tab, bool prepacked,
-                            hipStream_t st) {
-  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, prepacked, st);
+                            const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
+                            float ln_eps, hipStream_t st) {
+  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, prepacked, rstd, ln_eps, st);
 }
+
+// whole rows in one block: what the fused LayerNorm epilogue needs
+bool pp_h2_fwd_ln_supported(const PPShape& sh) { return pp_bf3_supported(sh) && sh.O <= 256; }
 
 // fp16x2 forward layout only (header | P), absmax included: first half of pp_pack_weights
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh) {

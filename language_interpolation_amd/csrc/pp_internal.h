@@ -61,8 +61,9 @@ size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                              const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
-                            const PPShape& sh, const BasisTab& tab, bool prepacked,
-                            hipStream_t st);
+                            const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
+                            float ln_eps, hipStream_t st);
+bool pp_h2_fwd_ln_supported(const PPShape& sh);
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh);
 void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st);
 size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh);

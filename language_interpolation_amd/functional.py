@@ -242,6 +242,75 @@ def piecewise_poly(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> torch.T
     return PiecewisePolyFunction.apply(x, w, spec)
 
 
+def layer_norm_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> bool:
+    """True when `LayerNorm(piecewise_poly(x, w))` has the fused kernel and that kernel is
+    what the automatic method choice would run for the layer alone."""
+    if spec.fwd_method != "auto" or spec.bwd_x_method != "auto" or x.dim() != 2 or \
+            not x.is_cuda or x.shape[0] == 0:
+        return False
+    O, I, _ = w.shape
+    return bool(_lib.load().pp_forward_layer_norm_supported(
+        x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous)))
+
+
+class PiecewisePolyLayerNormFunction(torch.autograd.Function):
+    """y = LayerNorm_lastdim(piecewise_poly(x, w)), the normalisation fused into the forward
+    kernel's epilogue (the block that produces a row normalises it before storing); backward =
+    the LayerNorm backward kernel, then the layer's two backward kernels.  Saves (x, w, y, rstd):
+    the un-normalised layer output never exists in memory."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, w: torch.Tensor, spec: LayerSpec, eps: float):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        _require_gpu(w, "w")
+        x = x.contiguous()
+        w_t = kernel_layout(w.detach())
+        B, I = x.shape
+        O = w_t.shape[2]
+        packed = pack_weights(w_t, spec, B)
+        if packed is None:
+            raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
+        y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(B, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = lib.pp_forward_layer_norm_f32(
+                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(packed), packed.numel(), B, I, O,
+                spec.n, spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
+                spec.out_scale, eps, _stream(x.device))
+        _lib.check(rc, "pp_forward_layer_norm_f32")
+        ctx.spec = spec
+        ctx.packed = packed if ctx.needs_input_grad[0] else None
+        ctx.save_for_backward(x, w, y, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        lib = _lib.load()
+        x, w, y, rstd = ctx.saved_tensors
+        spec = ctx.spec
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        B, O = y.shape
+        g = torch.empty_like(y)  # gradient w.r.t. the layer's (never stored) raw output
+        with torch.cuda.device(y.device):
+            rc = lib.pp_layer_norm_bwd_f32(_ptr(y), _ptr(gy), _ptr(rstd), _ptr(g), B, O,
+                                           _stream(y.device))
+        _lib.check(rc, "pp_layer_norm_bwd_f32")
+        w_t = kernel_layout(w.detach())
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = backward_input_raw(x, g, w_t, spec, packed=ctx.packed)
+        if ctx.needs_input_grad[1]:
+            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec).permute(2, 0, 1)
+        return gx, gw, None, None
+
+
+def piecewise_poly_layer_norm(x, w, spec: LayerSpec, eps: float = 1e-5) -> torch.Tensor:
+    return PiecewisePolyLayerNormFunction.apply(x, w, spec, eps)
+
+
 # ---------------------------------------------------------------------------
 # row-wise normalisations between the layers (HIP kernels in csrc/pp_norm.hip)
 # ---------------------------------------------------------------------------

@@ -95,7 +95,7 @@ class _Piecewise(nn.Module):
             self.in_features, fwd, bwd_x, bwd_w)
         return self
 
-    def forward(self, x: Tensor) -> Tensor:
+    def _prepare(self, x: Tensor) -> Tensor:
         if x.dim() != 2:
             raise ValueError(
                 f"{type(self).__name__}.forward takes [batch, in_features], got {tuple(x.shape)}; "
@@ -106,7 +106,17 @@ class _Piecewise(nn.Module):
             x = x.to(torch.float32)
         if self.periodicity is not None:
             x = make_periodic(x, self.periodicity)
-        return PF.piecewise_poly(x, self.w, self._spec)
+        return x
+
+    def forward(self, x: Tensor) -> Tensor:
+        return PF.piecewise_poly(self._prepare(x), self.w, self._spec)
+
+    def forward_layer_norm(self, x: Tensor, eps: float = 1e-5):
+        """`LazyLayerNormLastDim()(self(x))` in one kernel when this layer has the fused
+        epilogue (None otherwise: the caller then runs the two modules)."""
+        if x.dim() != 2 or not PF.layer_norm_fusable(x, self.w, self._spec):
+            return None
+        return PF.piecewise_poly_layer_norm(self._prepare(x), self.w, self._spec, eps)
 
     def extra_repr(self) -> str:
         kind = "discontinuous" if self._discontinuous else "continuous"
@@ -182,10 +192,12 @@ class LazyLayerNormLastDim(nn.Module):
     are never trained, so this is a non-affine LayerNorm.
     """
 
+    EPS = 1e-5
+
     def __init__(self, bias: bool = True):
         super().__init__()
         self.weight = None
         self.bias = bias
 
     def forward(self, input: Tensor) -> Tensor:
-        return PF.layer_norm_last(input, 1e-5)
+        return PF.layer_norm_last(input, self.EPS)

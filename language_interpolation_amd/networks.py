@@ -14,7 +14,7 @@ from typing import Callable, Optional
 import torch.nn as nn
 from torch import Tensor
 
-from .layers import high_order_fc_layers
+from .layers import LazyLayerNormLastDim, high_order_fc_layers
 
 
 class HighOrderMLP(nn.Module):
@@ -72,7 +72,22 @@ class HighOrderMLP(nn.Module):
         self.model = nn.Sequential(*layer_list)
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.model(x)
+        # same result as self.model(x); a polynomial layer directly followed by
+        # LazyLayerNormLastDim runs as one kernel where the layer has the fused epilogue
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if i + 1 < len(mods) and isinstance(mods[i + 1], LazyLayerNormLastDim) and \
+                    hasattr(m, "forward_layer_norm"):
+                fused = m.forward_layer_norm(x, LazyLayerNormLastDim.EPS)
+                if fused is not None:
+                    x = fused
+                    i += 2
+                    continue
+            x = m(x)
+            i += 1
+        return x
 
 
 class LowOrderMLP(nn.Module):

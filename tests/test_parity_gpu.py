@@ -258,6 +258,61 @@ def test_fp16x2_all_instantiations_large_batch(combo, O):
     check(hip_all(x, w, gy, n, S, disc), ref, "auto large")   # pre-split weights + auto
 
 
+@pytest.mark.parametrize("shape", [(300, 250, 250, 3, 2, False), (9000, 250, 250, 3, 2, False),
+                                   (8300, 250, 128, 3, 2, False), (700, 40, 70, 2, 4, True),
+                                   (513, 64, 256, 4, 2, False)],
+                         ids=lambda s: "-".join(str(v) for v in s))
+def test_fused_layer_norm_epilogue(shape):
+    """layer -> LazyLayerNormLastDim as one kernel: forward and all gradients against the
+    two-module path on the GPU and against the fp64 oracle."""
+    from oracle import pp_oracle as po
+    PF = _pf()
+    B, I, O, n, S, disc = shape
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=30)
+    spec = PF.make_spec(n, S, disc)
+    xd = x.cuda().requires_grad_(True)
+    wd = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1).requires_grad_(True)
+    assert PF.layer_norm_fusable(xd, wd, spec)
+    y = PF.piecewise_poly_layer_norm(xd, wd, spec, 1e-5)
+    y.backward(gy.cuda())
+    x2 = x.cuda().requires_grad_(True)
+    w2 = wd.detach().clone().requires_grad_(True)
+    y2 = PF.layer_norm_last(PF.piecewise_poly(x2, w2, spec), 1e-5)
+    y2.backward(gy.cuda())
+    assert rel_err(y.detach().cpu(), y2.detach().cpu()) <= 2e-6
+    assert rel_err(xd.grad.cpu(), x2.grad.cpu()) <= 2e-5
+    assert rel_err(wd.grad.cpu(), w2.grad.cpu()) <= 2e-5
+    xo = x.float().clone().requires_grad_(True)   # fp32 leaf: the oracle takes ids from fp32
+    wo = w.double().requires_grad_(True)
+    yo = po.layer_norm_last_dim(po.piecewise_forward_f64(xo, wo, n, S, disc), 1e-5)
+    yo.backward(gy.double())
+    assert rel_err(y.detach().cpu(), yo.detach()) <= TOL
+    assert rel_err(xd.grad.cpu(), xo.grad) <= 1e-4   # through the LayerNorm backward
+    assert rel_err(wd.grad.cpu(), wo.grad) <= 1e-4
+
+
+def test_fused_layer_norm_out_of_range_basis_and_network_equivalence():
+    import language_interpolation_amd as L
+    PF = _pf()
+    # far extrapolation in one row: the block recomputes its tile in fp32 and normalises it
+    x, w, gy = make_inputs(300, 250, 250, 3, 2, False, "normal", seed=31)
+    x[17, 5] = 900.0
+    spec = PF.make_spec(3, 2, False)
+    wd = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    y = PF.piecewise_poly_layer_norm(x.cuda(), wd, spec, 1e-5)
+    y2 = PF.layer_norm_last(PF.piecewise_poly(x.cuda(), wd, PF.make_spec(3, 2, False, fwd_method="dense")), 1e-5)
+    assert rel_err(y.cpu(), y2.cpu()) <= TOL
+    # HighOrderMLP.forward (fused pairs) == its Sequential run module by module
+    torch.manual_seed(0)
+    net = L.HighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=128, hidden_layers=2,
+                         hidden_width=250, in_segments=128, out_segments=2, hidden_segments=2,
+                         n_in=2, normalization=L.LazyLayerNormLastDim, device="cuda")
+    xb = (torch.rand(600, 16) * 2 - 1).cuda()
+    a = net(xb)
+    b = net.model(xb)
+    assert rel_err(a.detach().cpu(), b.detach().cpu()) <= 1e-5
+
+
 def test_prepacked_weights_match_per_call_packing():
     """pp_pack_weights_f32 + PP_WS_PREPACKED give bit-identical results to the per-call path."""
     PF = _pf()
