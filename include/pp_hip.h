@@ -193,6 +193,23 @@ int pp_max_abs_norm_fwd_f32(const float* x, float* y, int B, int D, float eps, v
 int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, int D, float eps,
                             void* stream);
 
+/* Selective scan of the reference's Mamba block (state_space_network.py:372-420: the Python
+ * loop over the sequence in MambaBlock.selective_scan):
+ *   x_t = exp(delta_t * A) * x_{t-1} + delta_t * B_t * u_t ;  y_t = <C_t, x_t> + D * u_t
+ * u, delta, y: [b][l][d];  A: [d][n];  Bm, Cm: [b][l][n];  D: [d]  (fp32, contiguous).
+ * xhist: optional [b][l][n][d] buffer that receives every x_t (the backward needs it; NULL
+ * for inference).  The backward returns gu, gdelta [b][l][d], gB, gC [b][l][n], gD [d] and the
+ * gradient of A TRANSPOSED, gA_t [n][d] (coalesced atomics; see csrc/pp_scan.hip).  All are
+ * overwritten; sums over channels / batch use float atomics, so the low bits of gA_t, gB, gC,
+ * gD depend on arrival order. */
+int pp_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, float* y, float* xhist, int b, int l,
+                              int d, int n, void* stream);
+int pp_selective_scan_bwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, const float* gy, const float* xhist,
+                              float* gu, float* gdelta, float* gA_t, float* gB, float* gC, float* gD,
+                              int b, int l, int d, int n, void* stream);
+
 /* Which method PP_METHOD_AUTO resolves to for a shape (for logs and tests).
  * pass: 0 forward, 1 backward-input, 2 backward-weight. */
 int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous);

@@ -9,6 +9,7 @@ from .layers import (  # noqa: F401
     fc_layers,
     high_order_fc_layers,
 )
+from .mamba import Mamba  # noqa: F401
 from .networks import HighOrderMLP, LowOrderMLP  # noqa: F401
 from .utils import reshape_apply  # noqa: F401
 
@@ -19,6 +20,7 @@ __all__ = [
     "fc_layers",
     "HighOrderMLP",
     "LowOrderMLP",
+    "Mamba",
     "MaxAbsNormalizationLast",
     "MaxCenterNormalizationLast",
     "LazyLayerNormLastDim",

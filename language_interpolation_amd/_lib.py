@@ -71,6 +71,8 @@ SIGNATURES = {
     "pp_layer_norm_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "pp_max_abs_norm_fwd_f32": (c_int, [_P, _P, c_int, c_int, c_float, _P]),
     "pp_max_abs_norm_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
+    "pp_selective_scan_fwd_f32": (c_int, [_P] * 8 + [c_int] * 4 + [_P]),
+    "pp_selective_scan_bwd_f32": (c_int, [_P] * 14 + [c_int] * 4 + [_P]),
     "pp_transpose_w_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "pp_transpose_wt_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
 }

@@ -350,6 +350,35 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
          sh.B >= 256;
 }
 
+static int scan_args_ok(int b, int l, int d, int n) {
+  if (b < 1 || l < 1 || d < 1 || n < 1 || b > 65535) return PP_ERR_SHAPE;
+  if ((long)b * l * d >= (1L << 31) || (long)b * l * n >= (1L << 31)) return PP_ERR_RANGE;
+  return PP_OK;
+}
+
+int pp_selective_scan_fwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, float* y, float* xhist, int b, int l,
+                              int d, int n, void* stream) {
+  if (!u || !delta || !A || !Bm || !Cm || !D || !y) return PP_ERR_NULL;
+  int rc = scan_args_ok(b, l, d, n);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_scan_fwd(u, delta, A, Bm, Cm, D, y, xhist, b, l, d, n,
+                                   (hipStream_t)stream));
+}
+
+int pp_selective_scan_bwd_f32(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, const float* gy, const float* xhist,
+                              float* gu, float* gdelta, float* gA_t, float* gB, float* gC, float* gD,
+                              int b, int l, int d, int n, void* stream) {
+  if (!u || !delta || !A || !Bm || !Cm || !D || !gy || !xhist || !gu || !gdelta || !gA_t || !gB ||
+      !gC || !gD)
+    return PP_ERR_NULL;
+  int rc = scan_args_ok(b, l, d, n);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_scan_bwd(u, delta, A, Bm, Cm, D, gy, xhist, gu, gdelta, gA_t, gB, gC, gD,
+                                   b, l, d, n, (hipStream_t)stream));
+}
+
 int pp_layer_norm_fwd_f32(const float* x, float* y, float* rstd, int B, int D, float eps,
                           void* stream) {
   if (!x || !y || !rstd) return PP_ERR_NULL;

@@ -55,6 +55,15 @@ hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float e
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
 
+// ---- Mamba selective scan (pp_scan.hip) ----
+hipError_t pp_launch_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, float* y, float* xhist, int b, int l,
+                              int d, int n, hipStream_t st);
+hipError_t pp_launch_scan_bwd(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, const float* gy, const float* xhist,
+                              float* gu, float* gdelta, float* gA_t, float* gB, float* gC, float* gD,
+                              int b, int l, int d, int n, hipStream_t st);
+
 // ---- dense path on bf16 MFMA with a 3-way fp32 split (pp_bf3_fwd.hip, pp_bf3_bwdx.hip, pp_bf3_bwdw.hip; shared: pp_bf3_common.h) ----
 bool pp_bf3_supported(const PPShape& sh);
 size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);

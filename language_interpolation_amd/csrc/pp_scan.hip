@@ -1,0 +1,169 @@
+// Selective scan of the reference's Mamba block, forward and backward.
+//
+//   x_t[d,s] = exp(delta_t[d] * A[d,s]) * x_{t-1}[d,s] + delta_t[d] * B_t[s] * u_t[d]
+//   y_t[d]   = sum_s C_t[s] * x_t[d,s] + D[d] * u_t[d]
+//
+// (state_space_network.py:372-420 of the reference: a Python loop over t that launches a
+// handful of elementwise kernels and an einsum per step, on [b, d, l, n] temporaries.)
+//
+// Layout of the work: lane = channel d, one wave per (64 channels, batch row); the states of a
+// channel live in registers, 16 at a time (an outer loop over chunks of 16 states re-runs the
+// time loop, so any state count works).  u/delta/gy/y are read and written coalesced over d;
+// B_t, C_t, A are wave-uniform or per-lane rows.  The backward needs x_t for every t: the
+// forward writes them once to a caller-owned history buffer [b][l][n][d] (coalesced over d)
+// instead of recomputing the recurrence.  Sums over channels (gB, gC) are reduced across the
+// wave with DPP adds, then one 16-lane atomic per (wave, t, chunk of states); sums over the
+// batch (gA, gD) are one atomic instruction per (wave, state) at the end, into a TRANSPOSED
+// gA ([n][d]: the 64 lanes of an instruction hit one 256-byte run; [d][n] would put every lane
+// in its own cache line, which the atomic units serve ~17x slower).
+#include "pp_device.h"
+
+namespace {
+
+constexpr int kSC = 16;  // states held in registers at a time
+
+__global__ __launch_bounds__(64) void pp_scan_fwd_kernel(const float* __restrict__ u,
+                                                          const float* __restrict__ delta,
+                                                          const float* __restrict__ A,
+                                                          const float* __restrict__ Bm,
+                                                          const float* __restrict__ Cm,
+                                                          const float* __restrict__ D,
+                                                          float* __restrict__ y,
+                                                          float* __restrict__ xhist, int l, int d,
+                                                          int n) {
+  const int b = blockIdx.y;
+  const int ch = blockIdx.x * 64 + threadIdx.x;
+  const bool live = ch < d;
+  const int chc = live ? ch : d - 1;
+  const float Dv = D[chc];
+  for (int c0 = 0; c0 < n; c0 += kSC) {
+    float a[kSC], x[kSC];
+#pragma unroll
+    for (int j = 0; j < kSC; ++j) {
+      a[j] = c0 + j < n ? A[(size_t)chc * n + c0 + j] : 0.0f;
+      x[j] = 0.0f;
+    }
+    for (int t = 0; t < l; ++t) {
+      const size_t row = (size_t)b * l + t;
+      const float dt = delta[row * d + chc];
+      const float uu = u[row * d + chc];
+      const float du = dt * uu;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kSC; ++j) {
+        if (c0 + j < n) {  // wave-uniform
+          const float bv = Bm[row * n + c0 + j];
+          const float cv = Cm[row * n + c0 + j];
+          x[j] = fmaf(expf(dt * a[j]), x[j], du * bv);
+          acc = fmaf(x[j], cv, acc);
+          if (xhist && live) xhist[(row * n + c0 + j) * d + ch] = x[j];
+        }
+      }
+      if (live) {
+        if (c0 == 0) y[row * d + ch] = fmaf(Dv, uu, acc);
+        else y[row * d + ch] += acc;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void pp_scan_bwd_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    const float* __restrict__ gy, const float* __restrict__ xhist, float* __restrict__ gu,
+    float* __restrict__ gdelta, float* __restrict__ gAt, float* __restrict__ gB,
+    float* __restrict__ gC, float* __restrict__ gD, int l, int d, int n) {
+  const int b = blockIdx.y;
+  const int ch = blockIdx.x * 64 + threadIdx.x;
+  const bool live = ch < d;
+  const int chc = live ? ch : d - 1;
+  const float Dv = D[chc];
+  float gd_acc = 0.0f;
+  for (int c0 = 0; c0 < n; c0 += kSC) {
+    float a[kSC], gx[kSC], ga[kSC], xt[kSC];
+#pragma unroll
+    for (int j = 0; j < kSC; ++j) {
+      a[j] = c0 + j < n ? A[(size_t)chc * n + c0 + j] : 0.0f;
+      gx[j] = 0.0f;  // d loss / d x_t, carried backwards
+      ga[j] = 0.0f;
+      // x_t of the step being processed (each history entry is read once: x_{t-1} loaded at
+      // step t is step t-1's x_t)
+      xt[j] = c0 + j < n ? xhist[(((size_t)b * l + l - 1) * n + c0 + j) * d + chc] : 0.0f;
+    }
+    for (int t = l - 1; t >= 0; --t) {
+      const size_t row = (size_t)b * l + t;
+      const float dt = delta[row * d + chc];
+      const float uu = u[row * d + chc];
+      const float g = live ? gy[row * d + chc] : 0.0f;
+      float gdt = 0.0f, guu = 0.0f;
+      float sumC = 0.0f, sumB = 0.0f;  // lane j keeps the channel sums of state c0 + j
+#pragma unroll
+      for (int j = 0; j < kSC; ++j) {
+        if (c0 + j < n) {  // wave-uniform
+          const float bv = Bm[row * n + c0 + j];
+          const float cv = Cm[row * n + c0 + j];
+          const float xp = t > 0 ? xhist[((row - 1) * n + c0 + j) * d + chc] : 0.0f;
+          const float e = expf(dt * a[j]);
+          gx[j] = fmaf(g, cv, gx[j]);
+          const float sc = pp_wave_sum(g * xt[j]);          // gC[b,t,s] = sum_d gy * x_t
+          const float sb = pp_wave_sum(gx[j] * dt * uu);    // gB[b,t,s] = sum_d gx * delta * u
+          if ((int)threadIdx.x == j) {
+            sumC = sc;
+            sumB = sb;
+          }
+          const float exp_xp = e * xp;
+          gdt = fmaf(gx[j], fmaf(a[j], exp_xp, bv * uu), gdt);
+          guu = fmaf(gx[j] * dt, bv, guu);
+          ga[j] = fmaf(gx[j] * dt, exp_xp, ga[j]);
+          gx[j] *= e;
+          xt[j] = xp;
+        }
+      }
+      // one 16-lane atomic per (wave, t, chunk) and tensor instead of one per state
+      if ((int)threadIdx.x < kSC && c0 + (int)threadIdx.x < n) {
+        atomicAdd(gC + row * n + c0 + threadIdx.x, sumC);
+        atomicAdd(gB + row * n + c0 + threadIdx.x, sumB);
+      }
+      if (live) {
+        if (c0 == 0) {
+          gdelta[row * d + ch] = gdt;
+          gu[row * d + ch] = fmaf(Dv, g, guu);
+          gd_acc = fmaf(g, uu, gd_acc);
+        } else {
+          gdelta[row * d + ch] += gdt;
+          gu[row * d + ch] += guu;
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < kSC; ++j)
+        if (c0 + j < n) atomicAdd(gAt + (size_t)(c0 + j) * d + ch, ga[j]);  // [n][d]: coalesced
+    }
+  }
+  if (live) atomicAdd(gD + ch, gd_acc);
+}
+
+}  // namespace
+
+hipError_t pp_launch_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, float* y, float* xhist, int b, int l,
+                              int d, int n, hipStream_t st) {
+  hipLaunchKernelGGL(pp_scan_fwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,
+                     Cm, D, y, xhist, l, d, n);
+  return hipGetLastError();
+}
+
+hipError_t pp_launch_scan_bwd(const float* u, const float* delta, const float* A, const float* Bm,
+                              const float* Cm, const float* D, const float* gy, const float* xhist,
+                              float* gu, float* gdelta, float* gAt, float* gB, float* gC, float* gD,
+                              int b, int l, int d, int n, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(gAt, 0, (size_t)d * n * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(gD, 0, (size_t)d * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(gB, 0, (size_t)b * l * n * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(gC, 0, (size_t)b * l * n * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pp_scan_bwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,
+                     Cm, D, gy, xhist, gu, gdelta, gAt, gB, gC, gD, l, d, n);
+  return hipGetLastError();
+}

@@ -409,3 +409,56 @@ def max_abs_norm_last(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     if _hip_norm_ok(x):
         return MaxAbsLastFunction.apply(x, eps)
     return x / (x.abs().max(dim=-1, keepdim=True)[0] + eps)
+
+
+class SelectiveScanFunction(torch.autograd.Function):
+    """Mamba's selective scan (state_space_network.py:372-420 of the reference) as one HIP
+    kernel per direction; the forward keeps every state x_t for the backward."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D):
+        lib = _lib.load()
+        for name, t in (("u", u), ("delta", delta), ("A", A), ("B", Bm), ("C", Cm), ("D", D)):
+            _require_gpu(t, name)
+        u, delta, A, Bm, Cm, D = (t.contiguous() for t in (u, delta, A, Bm, Cm, D))
+        b, l, d = u.shape
+        n = A.shape[1]
+        if delta.shape != u.shape or A.shape != (d, n) or Bm.shape != (b, l, n) or \
+                Cm.shape != (b, l, n) or D.shape != (d,):
+            raise ValueError("selective_scan: u, delta [b,l,d]; A [d,n]; B, C [b,l,n]; D [d]")
+        y = torch.empty_like(u)
+        need_grad = any(ctx.needs_input_grad)
+        xhist = torch.empty(b, l, n, d, device=u.device, dtype=torch.float32) if need_grad else None
+        if u.numel() > 0:
+            with torch.cuda.device(u.device):
+                rc = lib.pp_selective_scan_fwd_f32(_ptr(u), _ptr(delta), _ptr(A), _ptr(Bm), _ptr(Cm),
+                                                   _ptr(D), _ptr(y), _ptr(xhist), b, l, d, n,
+                                                   _stream(u.device))
+            _lib.check(rc, "pp_selective_scan_fwd_f32")
+        if need_grad:
+            ctx.save_for_backward(u, delta, A, Bm, Cm, D, xhist)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        u, delta, A, Bm, Cm, D, xhist = ctx.saved_tensors
+        b, l, d = u.shape
+        n = A.shape[1]
+        gy = gy.contiguous().float()
+        gu, gdelta = torch.empty_like(u), torch.empty_like(u)
+        gB, gC, gD = (torch.empty_like(t) for t in (Bm, Cm, D))
+        gA_t = torch.empty(n, d, device=u.device, dtype=torch.float32)
+        if u.numel() > 0:
+            with torch.cuda.device(u.device):
+                rc = lib.pp_selective_scan_bwd_f32(
+                    _ptr(u), _ptr(delta), _ptr(A), _ptr(Bm), _ptr(Cm), _ptr(D), _ptr(gy),
+                    _ptr(xhist), _ptr(gu), _ptr(gdelta), _ptr(gA_t), _ptr(gB), _ptr(gC), _ptr(gD),
+                    b, l, d, n, _stream(u.device))
+            _lib.check(rc, "pp_selective_scan_bwd_f32")
+        return gu, gdelta, gA_t.t(), gB, gC, gD
+
+
+def selective_scan(u, delta, A, Bm, Cm, D):
+    """y [b,l,d] from u, delta [b,l,d], A [d,n], B, C [b,l,n], D [d] (GPU fp32 only)."""
+    return SelectiveScanFunction.apply(u, delta, A, Bm, Cm, D)

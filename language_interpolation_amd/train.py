@@ -172,8 +172,15 @@ def select_network(cfg: Config, device=None) -> nn.Module:
                               non_linearity=nn.ReLU(), normalization=normalization,
                               device=device)]
         return nn.Sequential(*layers)
+    if net.model_type == "mamba":  # networks.py:918-934
+        from .mamba import Mamba
+        return Mamba(d_model=net.d_model, n_layer=net.n_layer, vocab_size=net.vocab_size,
+                     d_state=net.d_state, expand=net.expand, dt_rank=net.dt_rank,
+                     d_conv=net.d_conv, pad_vocab_size_multiple=net.pad_vocab_size_multiple,
+                     conv_bias=net.conv_bias, bias=net.bias, layer_type=net.layer_type, n=net.n,
+                     segments=net.segments, hidden_layers=net.hidden_layers).to(device)
     raise ValueError(f"model_type {net.model_type!r} is outside the hot path "
-                     "(supported: high_order, high_order_input)")
+                     "(supported: high_order, high_order_input, mamba)")
 
 
 # ---------------------------------------------------------------------------
@@ -243,6 +250,23 @@ class ASCIIPredictionNet(nn.Module):
         raise ValueError(f"Optimizer {opt.name} not recognized")
 
 
+class MambaASCIIPredictionNet(ASCIIPredictionNet):
+    """`MambaASCIIPredictionNet` (networks.py:135-147, :969-980): a target per position."""
+
+    def eval_step(self, batch):
+        x, y = batch[0], batch[1]
+        y_hat = self(x)
+        loss = self.loss(y_hat.reshape(y.shape[0] * y.shape[1], -1), y.flatten())
+        accuracy = (torch.argmax(y_hat, dim=2, keepdim=True) == y).float().mean()
+        return loss, accuracy
+
+
+def prediction_net(cfg: Config, device=None) -> ASCIIPredictionNet:
+    """The module examples/high_order_interpolation.py:162-165 builds for cfg.net.model_type."""
+    cls = MambaASCIIPredictionNet if cfg.net.model_type == "mamba" else ASCIIPredictionNet
+    return cls(cfg, device)
+
+
 # ---------------------------------------------------------------------------
 # data: character windows gathered on the device
 # ---------------------------------------------------------------------------
@@ -280,6 +304,26 @@ class CharWindows:
         return self.batch(idx)
 
 
+class CharSequences(CharWindows):
+    """Windows of ``max_features`` characters as indices; features = all but the last, targets
+    = all but the first (MambaMixin.collate_fn, lightning_datamodule.py:272-291, as_index)."""
+
+    def __init__(self, text, max_features: int, device="cuda"):
+        super().__init__(text, max_features - 1, device)
+
+    def batch(self, idx: torch.Tensor):
+        idx = idx.to(self.buf.device)
+        win = self.buf[idx.unsqueeze(1) + torch.arange(self.features + 1, device=self.buf.device)]
+        win = win.long().unsqueeze(2)
+        return win[:, :-1], win[:, 1:], idx
+
+
+def make_data(cfg: Config, text, device="cuda") -> CharWindows:
+    if cfg.net.model_type == "mamba":
+        return CharSequences(text, cfg.data.max_features, device)
+    return CharWindows(text, cfg.net.features, device)
+
+
 def synthetic_text(nchar: int, seed: int = 0) -> bytes:
     """Printable-ASCII text with word structure (no dataset ships with the build)."""
     g = torch.Generator().manual_seed(seed)
@@ -295,8 +339,10 @@ def synthetic_text(nchar: int, seed: int = 0) -> bytes:
 # the loop
 # ---------------------------------------------------------------------------
 def fit(module: ASCIIPredictionNet, data: CharWindows, steps: int, batch_size: int,
-        seed: int = 0, log_every: int = 0):
-    """`steps` optimizer steps; returns the list of (loss, accuracy) per step."""
+        seed: int = 0, log_every: int = 0, gradient_clip: Optional[float] = None):
+    """`steps` optimizer steps; returns the list of (loss, accuracy) per step.
+    `gradient_clip`: max gradient norm (the Trainer's gradient_clip_val,
+    examples/high_order_interpolation.py:158; `gradient_clip: null` in the root config)."""
     import torch.distributed as dist
 
     from .parallel import GradAllReducer, broadcast_parameters
@@ -318,6 +364,8 @@ def fit(module: ASCIIPredictionNet, data: CharWindows, steps: int, batch_size: i
         loss.backward()
         if reducer is not None:
             reducer.finish()
+        if gradient_clip:
+            torch.nn.utils.clip_grad_norm_(module.parameters(), gradient_clip)
         optimizer.step()
         history.append((loss.detach(), acc.detach()))
         if log_every and rank == 0 and (step + 1) % log_every == 0:
@@ -337,9 +385,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
     cfg = load_config(args.config, args.overrides)
     text = open(args.text, "rb").read() if args.text else synthetic_text(1 << 20)
-    module = ASCIIPredictionNet(cfg, device="cuda")
-    data = CharWindows(text, cfg.net.features, device="cuda")
-    hist = fit(module, data, args.steps, cfg.batch_size, log_every=max(1, args.steps // 10))
+    module = prediction_net(cfg, device="cuda")
+    data = make_data(cfg, text, device="cuda")
+    hist = fit(module, data, args.steps, cfg.batch_size, log_every=max(1, args.steps // 10),
+               gradient_clip=cfg.get("gradient_clip"))
     print(json.dumps({"final_loss": hist[-1][0], "final_acc": hist[-1][1], "steps": len(hist)}))
 
 

@@ -78,3 +78,15 @@ def test_char_windows_match_reference_construction():
     xs, ys, ids = data.sample(5, torch.Generator().manual_seed(1))
     assert xs.shape == (5, F) and ys.shape == (5, 1) and ids.max() < len(data)
     assert len(T.synthetic_text(1000)) == 1000
+
+
+def test_char_sequences_shifted_targets_and_mamba_config():
+    text = "The quick brown fox jumps over the lazy dog."
+    data = T.CharSequences(text, 6, device="cpu")
+    x, y, _ = data.batch(torch.tensor([0, 4]))
+    assert x.shape == (2, 5, 1) and y.shape == (2, 5, 1) and x.dtype == torch.long
+    assert x[1, :, 0].tolist() == [ord(c) for c in text[4:9]]
+    assert y[1, :, 0].tolist() == [ord(c) for c in text[5:10]]   # features shifted by one
+    cfg = T.load_config(CFG, ["net=mamba", "net.n_layer=2", "data.max_features=16"])
+    assert cfg.net.model_type == "mamba" and cfg.net.dt_rank == "auto" and cfg.net.d_state == 32
+    assert isinstance(T.make_data(cfg, text, device="cpu"), T.CharSequences)
