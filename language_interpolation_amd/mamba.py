@@ -6,7 +6,7 @@ dt_proj,A_log,D,out_proj}``, ``layers.<i>.norm.weight``, ``norm_f.weight``, tied
 and tensor shapes.  The four projections of a block are ``HighOrderMLP`` (two piecewise-
 polynomial layers each: the hot path) unless ``layer_type == "linear"``; the time loop of
 ``selective_scan`` (:372-420) is one HIP kernel per direction (csrc/pp_scan.hip).  Embedding,
-depthwise conv, SiLU / softplus and RMSNorm stay torch ops.
+SiLU / softplus and RMSNorm stay torch ops; the depthwise conv is k shifted multiply-adds.
 """
 from __future__ import annotations
 
@@ -31,6 +31,20 @@ def layer_generator(layer_type, in_width, out_width, segments, n, bias, hidden_l
     return HighOrderMLP(layer_type=layer_type, in_width=in_width, out_width=out_width,
                         hidden_width=out_width, hidden_layers=hidden_layers, n=n,
                         in_segments=segments, out_segments=segments, hidden_segments=segments)
+
+
+def causal_depthwise_conv(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """``conv1d(x^T)[:, :, :l]^T`` of the reference (:315-322: depthwise, padding k-1, truncated
+    to l, i.e. causal) on [b, l, d] directly, as k shifted multiply-adds.  MIOpen runs this
+    depthwise shape as one im2col + GEMM per batch row (16384 launches per step at b=1024)."""
+    k = weight.shape[-1]
+    l = x.shape[1]
+    xp = F.pad(x, (0, 0, k - 1, 0))
+    w = weight[:, 0, :]  # [d, k]
+    y = xp[:, 0:l] * w[:, 0]
+    for j in range(1, k):
+        y = y + xp[:, j:j + l] * w[:, j]
+    return y if bias is None else y + bias
 
 
 class RMSNorm(nn.Module):
@@ -63,9 +77,8 @@ class MambaBlock(nn.Module):
         self.out_proj = layer_generator(in_width=d_inner, out_width=d_model, bias=bias, **kw)
 
     def forward(self, x):
-        l = x.shape[1]
         x, res = reshape_apply(x, self.in_proj).split([self.d_inner, self.d_inner], dim=-1)
-        x = self.conv1d(x.transpose(1, 2))[:, :, :l].transpose(1, 2)
+        x = causal_depthwise_conv(x, self.conv1d.weight, self.conv1d.bias)
         y = self.ssm(F.silu(x)) * F.silu(res)
         return reshape_apply(y, self.out_proj)
 
