@@ -148,20 +148,41 @@ def step_bytes(B):
     return total
 
 
-def train_chars_per_s(net, dev, B, steps, world, reducer):
+class _TrainModule(torch.nn.Module):
+    """eval_step of ASCIIPredictionNet (cross entropy, accuracy) around an existing network."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.model = net
+        self.loss = torch.nn.CrossEntropyLoss()
+
+    def eval_step(self, batch):
+        y_hat = self.model(batch[0])
+        y = batch[1].flatten()
+        return self.loss(y_hat, y), (torch.argmax(y_hat, dim=1) == y).float().mean()
+
+
+def train_chars_per_s(net, dev, B, steps, world, reducer, graph):
     """The other half of BASELINE's metric: optimizer steps of the same network on character
-    windows gathered on the device (cross entropy, Adam), eager launches."""
-    from language_interpolation_amd.train import CharWindows, synthetic_text
+    windows gathered on the device (cross entropy, Adam).  One process: the step is replayed
+    from a HIP graph (train.GraphedTrainStep); several: eager launches with the RCCL
+    all-reduce of the gradients overlapping the backward."""
+    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, synthetic_text
 
     data = CharWindows(synthetic_text(1 << 20, seed=7), 16, device=dev)
-    gen = torch.Generator().manual_seed(11)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    ce = torch.nn.CrossEntropyLoss()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    module = _TrainModule(net)
+    graph = graph and reducer is None
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=graph)
+    graphed = GraphedTrainStep(module, opt, data.sample(B, gen)) if graph else None
 
     def one():
-        xb, yb, _ = data.sample(B, gen)
+        batch = data.sample(B, gen)
+        if graphed is not None:
+            graphed(batch)
+            return
         opt.zero_grad(set_to_none=True)
-        ce(net(xb), yb.flatten()).backward()
+        module.eval_step(batch)[0].backward()
         if reducer is not None:
             reducer.finish()
         opt.step()
@@ -305,7 +326,7 @@ def main():
     train_cps = None
     if args.train_steps > 0:
         graph = graph  # (the captured graph keeps its own buffers; training runs eager)
-        train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer)
+        train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer, not args.no_graph)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -333,7 +354,7 @@ def main():
             },
         }
         if train_cps is not None:
-            out["train_chars_per_s"] = round(train_cps, 1)  # cross entropy + Adam, eager
+            out["train_chars_per_s"] = round(train_cps, 1)  # cross entropy + Adam (graph replay at N=1)
         hb = step_bytes(B)
         out["hbm_roofline"] = {"algorithmic_bytes_per_step": hb,
                                "achieved_GBs": round(hb / (dt / args.steps) * 1e-9, 1),

@@ -239,10 +239,11 @@ class ASCIIPredictionNet(nn.Module):
         accuracy = (torch.argmax(y_hat, dim=1) == y.flatten()).float().mean()
         return loss, accuracy
 
-    def configure_optimizers(self):
+    def configure_optimizers(self, capturable: bool = False):
+        """`capturable`: keep Adam's step count on the device (needed under HIP graph capture)."""
         opt = self.cfg.optimizer
         if opt.name == "adam":
-            return torch.optim.Adam(self.parameters(), lr=opt.lr)
+            return torch.optim.Adam(self.parameters(), lr=opt.lr, capturable=capturable)
         if opt.name == "lion":
             return Lion(self.parameters(), lr=opt.lr, weight_decay=0.0)
         if opt.name == "sparse_lion":
@@ -300,7 +301,11 @@ class CharWindows:
         return x, y, idx
 
     def sample(self, batch_size: int, generator=None):
-        idx = torch.randint(0, self.n, (batch_size,), generator=generator)
+        """Random windows.  With a generator on the buffer's device the indices never exist on
+        the host (a host-side draw costs a blocking copy per step, which keeps the next step's
+        launches from being queued behind the running one)."""
+        dev = generator.device if generator is not None else self.buf.device
+        idx = torch.randint(0, self.n, (batch_size,), generator=generator, device=dev)
         return self.batch(idx)
 
 
@@ -338,9 +343,62 @@ def synthetic_text(nchar: int, seed: int = 0) -> bytes:
 # ---------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------
+class GraphedTrainStep:
+    """One optimizer step (forward, loss, backward, clip, optimizer) captured once in a HIP
+    graph and replayed on batches copied into static tensors: the step of these small networks
+    is a few hundred short launches, and the host cannot issue them as fast as the GPU retires
+    them.  The library allocates nothing and never synchronises, so the whole step is
+    capturable; torch's allocations inside the capture come from the graph's private pool.
+
+    The warm-up iterations PyTorch asks for before a capture run real steps, so parameters are
+    restored and the optimizer state is zeroed in place afterwards (state tensors must exist
+    before the capture, or their initialisation would be replayed with every step)."""
+
+    def __init__(self, module: "ASCIIPredictionNet", optimizer, example_batch,
+                 gradient_clip: Optional[float] = None, warmup: int = 3):
+        self.module, self.optimizer, self.clip = module, optimizer, gradient_clip
+        self.x = example_batch[0].clone()
+        self.y = example_batch[1].clone()
+        saved = [p.detach().clone() for p in module.parameters()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, q in zip(module.parameters(), saved):
+                p.copy_(q)
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.acc = self._body()
+
+    def _body(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, acc = self.module.eval_step((self.x, self.y))
+        loss.backward()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.module.parameters(), self.clip)
+        self.optimizer.step()
+        return loss.detach(), acc.detach()
+
+    def __call__(self, batch):
+        self.x.copy_(batch[0])
+        self.y.copy_(batch[1])
+        self.graph.replay()
+        return self.loss, self.acc
+
+
 def fit(module: ASCIIPredictionNet, data: CharWindows, steps: int, batch_size: int,
-        seed: int = 0, log_every: int = 0, gradient_clip: Optional[float] = None):
+        seed: int = 0, log_every: int = 0, gradient_clip: Optional[float] = None,
+        graph: bool = False):
     """`steps` optimizer steps; returns the list of (loss, accuracy) per step.
+    `graph`: replay the step from a HIP graph (single process only; see GraphedTrainStep).
     `gradient_clip`: max gradient norm (the Trainer's gradient_clip_val,
     examples/high_order_interpolation.py:158; `gradient_clip: null` in the root config)."""
     import torch.distributed as dist
@@ -349,25 +407,33 @@ def fit(module: ASCIIPredictionNet, data: CharWindows, steps: int, batch_size: i
 
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
-    gen = torch.Generator().manual_seed(seed + rank)
-    optimizer = module.configure_optimizers()
+    gen = torch.Generator(device=data.buf.device).manual_seed(seed + rank)
+    graph = graph and not distributed
+    optimizer = module.configure_optimizers(capturable=graph)
     reducer = None
     if distributed:
         broadcast_parameters(module)
         reducer = GradAllReducer(module.parameters())
     history = []
+    graphed = None
     t0 = time.perf_counter()
     for step in range(steps):
         batch = data.sample(batch_size, gen)
-        optimizer.zero_grad(set_to_none=True)
-        loss, acc = module.eval_step(batch)
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        if gradient_clip:
-            torch.nn.utils.clip_grad_norm_(module.parameters(), gradient_clip)
-        optimizer.step()
-        history.append((loss.detach(), acc.detach()))
+        if graph:
+            if graphed is None:
+                graphed = GraphedTrainStep(module, optimizer, batch, gradient_clip)
+            loss, acc = graphed(batch)
+            history.append((loss.clone(), acc.clone()))
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            loss, acc = module.eval_step(batch)
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            if gradient_clip:
+                torch.nn.utils.clip_grad_norm_(module.parameters(), gradient_clip)
+            optimizer.step()
+            history.append((loss.detach(), acc.detach()))
         if log_every and rank == 0 and (step + 1) % log_every == 0:
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -381,6 +447,7 @@ def main(argv=None):
     ap.add_argument("--config", required=True, help="root yaml in the reference's layout")
     ap.add_argument("--text", default=None, help="ASCII text file (default: synthetic text)")
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
     ap.add_argument("overrides", nargs="*", help="a.b=value, or group=name")
     args = ap.parse_args(argv)
     cfg = load_config(args.config, args.overrides)
@@ -388,7 +455,7 @@ def main(argv=None):
     module = prediction_net(cfg, device="cuda")
     data = make_data(cfg, text, device="cuda")
     hist = fit(module, data, args.steps, cfg.batch_size, log_every=max(1, args.steps // 10),
-               gradient_clip=cfg.get("gradient_clip"))
+               gradient_clip=cfg.get("gradient_clip"), graph=args.graph)
     print(json.dumps({"final_loss": hist[-1][0], "final_acc": hist[-1][1], "steps": len(hist)}))
 
 

@@ -108,3 +108,26 @@ def test_mamba_model_type_trains():
     first = sum(l for l, _ in hist[:5]) / 5
     last = sum(l for l, _ in hist[-5:]) / 5
     assert last < 0.5 * first, (first, last, hist[::10])
+
+
+@pytest.mark.parametrize("overrides", [
+    ["net=baseline_small_250", "net.hidden.width=64", "net.hidden.layers=1", "optimizer=adam",
+     "optimizer.lr=1e-3", "batch_size=512"],
+    ["net=mamba", "net.n_layer=1", "optimizer=lion", "optimizer.lr=1e-4", "batch_size=32",
+     "data.max_features=16"],
+])
+def test_graph_replayed_steps_match_eager_steps(overrides):
+    """fit(graph=True) replays the captured step; same init and batches as the eager loop give
+    the same losses (up to the arrival order of the float atomics)."""
+    from language_interpolation_amd import train as T
+    cfg = T.load_config(CFG, overrides)
+    text = b"the cat sat on the mat and the dog sat on the log. " * 40
+    hists = []
+    for graph in (False, True):
+        torch.manual_seed(5)
+        module = T.prediction_net(cfg, device="cuda")
+        data = T.make_data(cfg, text)
+        hists.append(T.fit(module, data, steps=12, batch_size=cfg.batch_size, seed=6, graph=graph))
+    for (le, ae), (lg, ag) in zip(*hists):
+        assert abs(le - lg) <= 2e-3 * max(1.0, abs(le)), (hists[0], hists[1])
+    assert hists[1][-1][0] < hists[1][0][0]

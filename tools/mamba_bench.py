@@ -44,7 +44,7 @@ Cm = torch.randn(b, l, n, device="cuda", generator=g, requires_grad=True)
 D = torch.ones(d, device="cuda", requires_grad=True)
 gy = torch.randn(b, l, d, device="cuda", generator=g)
 ins = [u, delta, A, Bm, Cm, D]
-for name, f in (("hip", PF.selective_scan), ("torch loop", torch_loop_scan)):
+for name, f in (() if os.environ.get("PP_MB_ONLY") else (("hip", PF.selective_scan), ("torch loop", torch_loop_scan))):
     def fwd_bwd():
         torch.autograd.grad(f(*ins), ins, gy)
     with torch.no_grad():
@@ -56,15 +56,23 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = T.load_config(os.path.join(root, "configs", "high_order_interpolation.yaml"),
                     ["net=mamba", "net.n_layer=2", "optimizer=adam", f"batch_size={b}", "data.max_features=16"])
 data = T.make_data(cfg, T.synthetic_text(1 << 20))
-for name in ("hip scan", "torch-loop scan"):
+VARIANTS = ("hip scan, graph replay", "hip scan", "torch-loop scan")
+if os.environ.get("PP_MB_ONLY"):
+    VARIANTS = tuple(v for v in VARIANTS if os.environ["PP_MB_ONLY"] in v)
+for name in VARIANTS:
     torch.manual_seed(0)
     module = T.prediction_net(cfg, device="cuda")
-    if name != "hip scan":
+    if name == "torch-loop scan":
         for blk in module.model.layers:
             blk.mixer.selective_scan = torch_loop_scan
-    opt = module.configure_optimizers()
-    gen = torch.Generator().manual_seed(0)
+    graph = "graph" in name
+    opt = module.configure_optimizers(capturable=graph)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    graphed = T.GraphedTrainStep(module, opt, data.sample(b, gen)) if graph else None
     def step():
+        if graphed is not None:
+            graphed(data.sample(b, gen))
+            return
         opt.zero_grad(set_to_none=True)
         loss, _ = module.eval_step(data.sample(b, gen))
         loss.backward()
