@@ -22,24 +22,29 @@ namespace {
 // ---------------------------------------------------------------------------
 constexpr int kSB = 32;  // steps per scale block
 
-// ranged pack: block = (scale block, 64 out columns); 4 step groups x 64 columns; every
-// thread holds its kSB/4 steps x 16 rows in registers between the max and the split pass
+// ranged pack: block = (scale block, kPackCols out columns); 256/kPackCols step groups x
+// kPackCols columns; every thread holds its steps x 16 rows in registers between the max and
+// the split pass.  32 columns: 256 blocks at 16384 rows x 256 outs (64 gave 128 blocks, half
+// the CUs idle, and twice the registers per thread).
+constexpr int kPackCols = 32;
+
 template <class SC>
 __global__ __launch_bounds__(256) void pp_split_pack_gy_ranged_kernel(
     const float* __restrict__ gy, float2* __restrict__ gscale, u32x4* __restrict__ G, int B, int O,
     int Opad, int nbs) {
-  __shared__ unsigned cmax[64];
+  __shared__ unsigned cmax[kPackCols];
+  constexpr int NG = 256 / kPackCols;  // step groups
   const int sb = blockIdx.x;
-  const int oc = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int o = blockIdx.y * 64 + oc;
-  if (threadIdx.x < 64) cmax[threadIdx.x] = 0u;
+  const int oc = threadIdx.x & (kPackCols - 1), tg = threadIdx.x / kPackCols;
+  const int o = blockIdx.y * kPackCols + oc;
+  if (threadIdx.x < kPackCols) cmax[threadIdx.x] = 0u;
   __syncthreads();
-  constexpr int PER = kSB / 4;
+  constexpr int PER = kSB / NG;
   float v[PER][16];
   unsigned mx = 0;
 #pragma unroll
   for (int m = 0; m < PER; ++m) {
-    const int t = sb * kSB + tg + 4 * m;
+    const int t = sb * kSB + tg + NG * m;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int b = 16 * t + j;
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void pp_split_pack_gy_ranged_kernel(
   if (tg == 0) gscale[(size_t)sb * Opad + o] = make_float2(sc, inv);
 #pragma unroll
   for (int m = 0; m < PER; ++m) {
-    const int t = sb * kSB + tg + 4 * m;
+    const int t = sb * kSB + tg + NG * m;
     if (t >= nbs) continue;
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[m][j] *= sc;
@@ -369,7 +374,7 @@ hipError_t launch_bwd_w_split(const float* x, const float* gy, float* gwt, void*
   char* base = static_cast<char*>(ws);
   u32x4* G = reinterpret_cast<u32x4*>(base + p.sc_bytes);
   if constexpr (SC::kRanged) {
-    hipLaunchKernelGGL(pp_split_pack_gy_ranged_kernel<SC>, dim3(p.nsb, p.opad / 64), dim3(256), 0,
+    hipLaunchKernelGGL(pp_split_pack_gy_ranged_kernel<SC>, dim3(p.nsb, p.opad / kPackCols), dim3(256), 0,
                        st, gy, reinterpret_cast<float2*>(base), G, sh.B, sh.O, p.opad, p.nbs);
   } else {
     const long nthr = (long)p.nbs * p.opad;
