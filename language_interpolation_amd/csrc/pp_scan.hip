@@ -12,7 +12,7 @@
 // B_t, C_t, A are wave-uniform or per-lane rows.  The backward needs x_t for every t: the
 // forward writes them once to a caller-owned history buffer [b][l][n][d] (coalesced over d)
 // instead of recomputing the recurrence.  Sums over channels (gB, gC) are reduced across the
-// wave with DPP adds, then one 16-lane atomic per (wave, t, chunk of states); sums over the
+// wave through LDS, then one 16-lane atomic per (wave, t, chunk of states); sums over the
 // batch (gA, gD) are one atomic instruction per (wave, state) at the end, into a TRANSPOSED
 // gA ([n][d]: the 64 lanes of an instruction hit one 256-byte run; [d][n] would put every lane
 // in its own cache line, which the atomic units serve ~17x slower).
@@ -67,62 +67,97 @@ __global__ __launch_bounds__(64) void pp_scan_fwd_kernel(const float* __restrict
   }
 }
 
+// quad sum (lanes 4q..4q+3), result in all four lanes: two DPP quad_perm adds
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
+  return v;
+}
+
 __global__ __launch_bounds__(64) void pp_scan_bwd_kernel(
     const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
     const float* __restrict__ gy, const float* __restrict__ xhist, float* __restrict__ gu,
     float* __restrict__ gdelta, float* __restrict__ gAt, float* __restrict__ gB,
     float* __restrict__ gC, float* __restrict__ gD, int l, int d, int n) {
+  // channel sums of the block's 16 states at one time step: every lane writes its 16 products
+  // ([state][lane], conflict-free), then lane L adds 16 consecutive lanes' values of state L/4
+  // and the four lanes of a state finish with a quad sum -- ~40 instructions per tensor and
+  // step instead of 16 full wave reductions.  One wave per block: LDS operations of a wave
+  // execute in order, so no barrier is needed between the write and the read phase.
+  __shared__ __align__(16) float red[2][kSC][64];
   const int b = blockIdx.y;
-  const int ch = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x * 64 + lane;
   const bool live = ch < d;
   const int chc = live ? ch : d - 1;
   const float Dv = D[chc];
+  const int rs = lane >> 2, rq = lane & 3;  // reduce role: state rs, quarter rq
   float gd_acc = 0.0f;
   for (int c0 = 0; c0 < n; c0 += kSC) {
-    float a[kSC], gx[kSC], ga[kSC], xt[kSC];
+    float a[kSC], gx[kSC], ga[kSC], xt[kSC], xp[kSC];
+    const size_t last = (size_t)b * l + l - 1;
 #pragma unroll
     for (int j = 0; j < kSC; ++j) {
-      a[j] = c0 + j < n ? A[(size_t)chc * n + c0 + j] : 0.0f;
+      const bool on = c0 + j < n;
+      a[j] = on ? A[(size_t)chc * n + c0 + j] : 0.0f;
       gx[j] = 0.0f;  // d loss / d x_t, carried backwards
       ga[j] = 0.0f;
-      // x_t of the step being processed (each history entry is read once: x_{t-1} loaded at
-      // step t is step t-1's x_t)
-      xt[j] = c0 + j < n ? xhist[(((size_t)b * l + l - 1) * n + c0 + j) * d + chc] : 0.0f;
+      // x_t and x_{t-1} of the step being processed; x_{t-2} is fetched under step t's
+      // arithmetic (each history entry is read once)
+      xt[j] = on ? xhist[(last * n + c0 + j) * d + chc] : 0.0f;
+      xp[j] = on && l > 1 ? xhist[((last - 1) * n + c0 + j) * d + chc] : 0.0f;
     }
+    float dt = delta[last * d + chc], uu = u[last * d + chc];
+    float g = live ? gy[last * d + chc] : 0.0f;
     for (int t = l - 1; t >= 0; --t) {
       const size_t row = (size_t)b * l + t;
-      const float dt = delta[row * d + chc];
-      const float uu = u[row * d + chc];
-      const float g = live ? gy[row * d + chc] : 0.0f;
+      // next step's operands
+      float xn[kSC], dt_n = 0.0f, uu_n = 0.0f, g_n = 0.0f;
+      if (t > 0) {
+        dt_n = delta[(row - 1) * d + chc];
+        uu_n = u[(row - 1) * d + chc];
+        g_n = live ? gy[(row - 1) * d + chc] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < kSC; ++j)
+        xn[j] = (t > 1 && c0 + j < n) ? xhist[((row - 2) * n + c0 + j) * d + chc] : 0.0f;
       float gdt = 0.0f, guu = 0.0f;
-      float sumC = 0.0f, sumB = 0.0f;  // lane j keeps the channel sums of state c0 + j
 #pragma unroll
       for (int j = 0; j < kSC; ++j) {
+        float pc = 0.0f, pb = 0.0f;
         if (c0 + j < n) {  // wave-uniform
           const float bv = Bm[row * n + c0 + j];
           const float cv = Cm[row * n + c0 + j];
-          const float xp = t > 0 ? xhist[((row - 1) * n + c0 + j) * d + chc] : 0.0f;
           const float e = expf(dt * a[j]);
           gx[j] = fmaf(g, cv, gx[j]);
-          const float sc = pp_wave_sum(g * xt[j]);          // gC[b,t,s] = sum_d gy * x_t
-          const float sb = pp_wave_sum(gx[j] * dt * uu);    // gB[b,t,s] = sum_d gx * delta * u
-          if ((int)threadIdx.x == j) {
-            sumC = sc;
-            sumB = sb;
-          }
-          const float exp_xp = e * xp;
+          pc = g * xt[j];            // gC[b,t,s] = sum_d gy * x_t
+          pb = gx[j] * dt * uu;      // gB[b,t,s] = sum_d gx * delta * u
+          const float exp_xp = e * xp[j];
           gdt = fmaf(gx[j], fmaf(a[j], exp_xp, bv * uu), gdt);
           guu = fmaf(gx[j] * dt, bv, guu);
           ga[j] = fmaf(gx[j] * dt, exp_xp, ga[j]);
           gx[j] *= e;
-          xt[j] = xp;
         }
+        red[0][j][lane] = pc;
+        red[1][j][lane] = pb;
       }
-      // one 16-lane atomic per (wave, t, chunk) and tensor instead of one per state
-      if ((int)threadIdx.x < kSC && c0 + (int)threadIdx.x < n) {
-        atomicAdd(gC + row * n + c0 + threadIdx.x, sumC);
-        atomicAdd(gB + row * n + c0 + threadIdx.x, sumB);
+      {
+        const float4* rc = reinterpret_cast<const float4*>(&red[0][rs][rq * 16]);
+        const float4* rb = reinterpret_cast<const float4*>(&red[1][rs][rq * 16]);
+        float sc = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 vc = rc[q], vb = rb[q];
+          sc += (vc.x + vc.y) + (vc.z + vc.w);
+          sb += (vb.x + vb.y) + (vb.z + vb.w);
+        }
+        sc = quad_sum(sc);
+        sb = quad_sum(sb);
+        if (rq == 0 && c0 + rs < n) {  // 16 lanes, 16 consecutive addresses
+          atomicAdd(gC + row * n + c0 + rs, sc);
+          atomicAdd(gB + row * n + c0 + rs, sb);
+        }
       }
       if (live) {
         if (c0 == 0) {
@@ -134,6 +169,14 @@ __global__ __launch_bounds__(64) void pp_scan_bwd_kernel(
           gu[row * d + ch] += guu;
         }
       }
+#pragma unroll
+      for (int j = 0; j < kSC; ++j) {
+        xt[j] = xp[j];
+        xp[j] = xn[j];
+      }
+      dt = dt_n;
+      uu = uu_n;
+      g = g_n;
     }
     if (live) {
 #pragma unroll
