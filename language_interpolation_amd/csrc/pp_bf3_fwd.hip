@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   constexpr int NX = NTILE > 1 ? NTILE / 2 : 1;  // tiles a wave hands over
   constexpr int kRedFloats = G == 2 ? 2 * 4 * NX * 16 * 64 : 0;
   float* red = reinterpret_cast<float*>(phiL);   // [g][cw][NX][16][64]
-  float* statL = red + kRedFloats;               // LayerNorm: [4G waves][ROWS] | mean | rstd
+  float* statL = red + kRedFloats;               // LayerNorm: [4G waves x 2][ROWS] | mean | rstd
   auto finish = [&](auto gc) {
     constexpr int GS = decltype(gc)::value;  // this wave's group
     auto kept = [](int T) { return G == 1 || (NTILE == 1 ? GS == 0 : (T & 1) == GS); };
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
     if (rstd_out) {
       // fused non-affine LayerNorm over the row (the block holds whole rows: grid.y == 1):
       // two passes (mean, then centred second moment), partial row sums per wave in LDS
-      float* meanL = statL + 4 * G * ROWS;
+      float* meanL = statL + 8 * G * ROWS;
       float* rsL = meanL + ROWS;
       auto row_pass = [&](bool centred) {
 #pragma unroll
@@ -303,15 +303,20 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
                 if (o0 + nt * 32 + r < sh.O) sacc += centred ? d * d : d;
               }
             });
-#pragma unroll
-            for (int dd = 16; dd > 0; dd >>= 1) sacc += __shfl_xor(sacc, dd);
-            if (r == 0) statL[wv * ROWS + rr] = sacc;
+            // sum over the 16 lanes of a DPP row (four full-rate adds; a __shfl_xor tree is
+            // five dependent LDS round trips per value and made this epilogue 13 us long);
+            // the two rows of a 32-column tile go to LDS separately
+            sacc = pp_dpp_add<0x128>(sacc);
+            sacc = pp_dpp_add<0x124>(sacc);
+            sacc = pp_dpp_add<0x122>(sacc);
+            sacc = pp_dpp_add<0x121>(sacc);
+            if ((r & 15) == 0) statL[(wv * 2 + (r >> 4)) * ROWS + rr] = sacc;
           }
         __syncthreads();
         if (threadIdx.x < ROWS) {
           float tot = 0.0f;
 #pragma unroll
-          for (int w = 0; w < 4 * G; ++w) tot += statL[w * ROWS + threadIdx.x];
+          for (int w = 0; w < 8 * G; ++w) tot += statL[w * ROWS + threadIdx.x];
           if (!centred) {
             meanL[threadIdx.x] = tot / (float)sh.O;
           } else {
@@ -389,7 +394,7 @@ hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y,
   size_t lds = (size_t)G * 2 * SC::PL * K * 2 * 32 * RM * 16;
   // epilogue: exchange area of the two groups + LayerNorm row statistics
   const size_t red = G == 2 ? (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4 : 0;
-  lds = std::max(lds, red + (size_t)(4 * G + 2) * 32 * RM * 4);
+  lds = std::max(lds, red + (size_t)(8 * G + 2) * 32 * RM * 4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
     static bool once = false;  // per instantiation

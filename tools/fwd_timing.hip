@@ -10,6 +10,7 @@ hipError_t pp_launch_segment_ids(const float*, int32_t*, const PPShape&, hipStre
 int main(int argc, char** argv) {
   int B = argc > 1 ? atoi(argv[1]) : 16384;
   int scheme = argc > 2 ? atoi(argv[2]) : 4;
+  int ln = argc > 3 ? atoi(argv[3]) : 0;
   PPShape sh{};
   sh.B = B; sh.I = 250; sh.O = 250; sh.n = 3; sh.S = 2; sh.K = 5; sh.stride = 2; sh.disc = 0;
   sh.length = 2.0f; sh.half = 1.0f; sh.Sf = 2.0f; sh.out_scale = 1.0f;
@@ -30,10 +31,11 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&x, hx.size() * 4); (void)hipMalloc(&w, hw.size() * 4);
   (void)hipMalloc(&y, (size_t)B * sh.O * 4);
   (void)hipMalloc(&ws, pp_bf3_fwd_workspace_bytes(sh));
+  float* rstd; (void)hipMalloc(&rstd, (size_t)B * 4);
   (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   for (int it = 0; it < 3; ++it) {
-    hipError_t e = scheme == 4 ? pp_launch_fwd_h2(x, w, y, nullptr, ws, sh, tab, nullptr)
+    hipError_t e = scheme == 4 ? pp_launch_fwd_h2(x, w, y, nullptr, ws, sh, tab, false, ln ? rstd : nullptr, 1e-5f, nullptr)
                                : pp_launch_fwd_bf3(x, w, y, nullptr, ws, sh, tab, nullptr);
     if (e != hipSuccess) { printf("launch failed %d\n", (int)e); return 1; }
   }
@@ -43,6 +45,7 @@ int main(int argc, char** argv) {
   (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(pp_dbg_times), t.size() * 8);
   unsigned long long t00 = ~0ull;
   for (int b = 0; b < nb; ++b) if (t[b * 8] < t00) t00 = t[b * 8];
+  printf("ln=%d ", ln);
   printf("scheme %d  block: start | prologue | main loop | exchange+store  (us)\n", scheme);
   double sum[4] = {0};
   for (int b = 0; b < nb; ++b) {
