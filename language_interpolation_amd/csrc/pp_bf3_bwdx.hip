@@ -143,7 +143,13 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
       for (int p = 0; p < PL; ++p)
         w[k][p] = __builtin_bit_cast(
             frag, __builtin_amdgcn_raw_buffer_load_b128(
-                      rq, vq_off, p * plane_bytes + t * t_bytes + k * k_bytes, 0));
+                      rq, vq_off,
+#ifdef PP_W_SAME  // developer experiment: every W load hits the same lines (L1-resident)
+                      p * plane_bytes + 0 * (t + k),
+#else
+                      p * plane_bytes + t * t_bytes + k * k_bytes,
+#endif
+                      0));
   };
   auto aload = [&](int buf, int tt, frag (&a)[RM][PL]) {
 #pragma unroll
@@ -224,8 +230,15 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
     // to their first use to save registers).  kOC % NWS == 0: set index = tt % NWS.
     auto step = [&](int tt, auto uc) {
       constexpr int U = decltype(uc)::value;
+#ifdef PP_STEP_TICKS
+      PP_STEP_TICK(c * kOC + tt)
+#endif
+#ifndef PP_NO_WLOAD
       wload(c * kOC + tt + D, W[(U + D) % NWS]);
+#endif
+#ifndef PP_NO_ALOAD
       aload(buf, min(tt + 1, kOC - 1), A[(U + 1) & 1]);  // (past the chunk: a harmless re-read)
+#endif
       __builtin_amdgcn_sched_barrier(0);
       mm(A[U & 1], W[U]);
       __builtin_amdgcn_sched_barrier(0);

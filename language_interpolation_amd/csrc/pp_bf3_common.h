@@ -281,8 +281,17 @@ __device__ unsigned long long pp_dbg_times[8 * 8192];
 #define PP_TICK(slot)                                                                   \
   if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192)                         \
     pp_dbg_times[blockIdx.x * 8 + (slot)] = wall_clock64();
+__device__ unsigned long long pp_dbg_steps[32 * 8192];
+// even slots: wall clock (100 MHz); odd slots: shader clock -- their ratio is the clock the
+// SIMD actually ran at between two stamps
+#define PP_STEP_TICK(idx)                                                               \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192 && (idx) < 16) {         \
+    pp_dbg_steps[blockIdx.x * 32 + 2 * (idx)] = wall_clock64();                         \
+    pp_dbg_steps[blockIdx.x * 32 + 2 * (idx) + 1] = clock64();                          \
+  }
 #else
 #define PP_TICK(slot)
+#define PP_STEP_TICK(idx)
 #endif
 
 #define PP_BF3_COMBOS(X) \

@@ -150,7 +150,13 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
       for (int nt = 0; nt < NT; ++nt)
         w[p][nt] = __builtin_bit_cast(
             frag, __builtin_amdgcn_raw_buffer_load_b128(
-                      rp, vcol[nt], p * plane_bytes + k * k_bytes + s * step_bytes, 0));
+                      rp, vcol[nt],
+#ifdef PP_W_SAME  // developer experiment: every W load hits the same lines (L1-resident)
+                      p * plane_bytes + 0 * (k + s),
+#else
+                      p * plane_bytes + k * k_bytes + s * step_bytes,
+#endif
+                      0));
   };
   auto aload = [&](int buf, int k, frag (&a)[RM][PL]) {
 #pragma unroll

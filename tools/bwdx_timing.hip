@@ -9,6 +9,7 @@ bool pp_dense_supported(const PPShape&) { return true; }
 hipError_t pp_launch_segment_ids(const float*, int32_t*, const PPShape&, hipStream_t) { return hipSuccess; }
 
 int main(int argc, char** argv) {
+  const float dscale = getenv("PP_DATA_SCALE") ? atof(getenv("PP_DATA_SCALE")) : 1.0f;
   int B = argc > 1 ? atoi(argv[1]) : 16384;
   PPShape sh{};
   sh.B = B; sh.I = 250; sh.O = 250; sh.n = 3; sh.S = 2; sh.K = 5; sh.stride = 2; sh.disc = 0;
@@ -54,6 +55,23 @@ int main(int argc, char** argv) {
     if (b < 4 || b % (nb / 8) == 0)
       printf("block %4d: %7.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", b, d[0], d[1],
              d[2], d[3], d[4], d[5], d[6], d[7]);
+  }
+  {
+    std::vector<unsigned long long> st(32 * 8192);
+    (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(pp_dbg_steps), st.size() * 8);
+    printf("step starts relative to the first step of the block (us), mean over blocks:\n");
+    double wall = 0, shader = 0;
+    for (int j = 0; j < 16; ++j) {
+      double a = 0;
+      for (int b = 0; b < nb; ++b) a += (double)(long long)(st[b * 32 + 2 * j] - st[b * 32]) * 0.01;
+      printf(" %5.2f", a / nb);
+    }
+    for (int b = 0; b < nb; ++b) {
+      wall += (double)(long long)(st[b * 32 + 14] - st[b * 32]) * 0.01;
+      shader += (double)(long long)(st[b * 32 + 15] - st[b * 32 + 1]);
+    }
+    printf("\nshader clock over steps 0..7: %.0f MHz", shader / wall);
+    printf("\n");
   }
   printf("mean      : %7.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", sum[0] / nb,
          sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb, sum[6] / nb, sum[7] / nb);
