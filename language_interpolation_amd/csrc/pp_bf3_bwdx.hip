@@ -284,16 +284,14 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
         const float xi = sh.length * ((xq - x_min) * dc.inv_w) - sh.half;
         float dl[N];
         pp_lagrange_dl<N>(xi, tab, dl);
+        // sum_j dl_j * T[s*stride + j]: pick the segment's N accumulators, then N fmas
         float gsum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-          float d = 0.0f;
+        for (int j = 0; j < N; ++j) {
+          float a = acc[j][rm][q];
 #pragma unroll
-          for (int sq = 0; sq < S; ++sq) {
-            const int j = k - sq * stride;
-            if (j >= 0 && j < N) d = (s == sq) ? dl[j] : d;
-          }
-          gsum = fmaf(d, acc[k][rm][q], gsum);
+          for (int sq = 1; sq < S; ++sq) a = (s == sq) ? acc[sq * stride + j][rm][q] : a;
+          gsum = fmaf(dl[j], a, gsum);
         }
         if constexpr (SC::kRanged)
           gsum *= rscL[lastbuf][rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h].y * wsinv;
