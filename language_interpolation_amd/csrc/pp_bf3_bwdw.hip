@@ -320,7 +320,7 @@ WPlan3 wplan3(const PPShape& sh) {
   WPlan3 p;
   // K x NT accumulators of 16 registers per wave; 32-out waves when O <= 128 so that
   // all four column waves have work
-  p.nt = (sh.K <= 6 && sh.O > 128) ? 2 : 1;
+  p.nt = (sh.K <= 5 && sh.O > 128) ? 2 : 1;  // K = 6 with two tiles: the accumulators go to scratch
   p.opad = ((sh.O + 63) / 64) * 64;
   p.ocols = (sh.O + 128 * p.nt - 1) / (128 * p.nt);
   const int tiles = ((sh.I + 31) / 32) * p.ocols;
@@ -387,7 +387,7 @@ hipError_t launch_bwd_w_split(const float* x, const float* gy, float* gwt, void*
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
     hipError_t e = hipErrorInvalidValue;                                                   \
-    if constexpr (K_ <= 6) {                                                               \
+    if constexpr (K_ <= 5) {                                                               \
       if (p.nt == 2)                                                                       \
         e = launch_bwd_w_bf3<SC, N_, K_, 2>(x, gy, ws, out, sh, tab, dc, p, scale, st);    \
     }                                                                                      \

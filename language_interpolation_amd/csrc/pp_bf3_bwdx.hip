@@ -368,14 +368,14 @@ hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, 
   dc.inv_len = 1.0f / sh.length;
   if (!prepacked) pack_wo_split<SC>(wt, ws, q_off, sh, true, st);
   // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
-  int rm = sh.B >= 4096 && sh.K <= 6 ? 2 : 1;
+  int rm = sh.B >= 4096 && sh.K <= 5 ? 2 : 1;  // K = 6 at 64 rows spills hundreds of registers
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
     const int c = atoi(v);
     if ((c == 1 || c == 2) && (c == 1 || sh.K <= 6)) rm = c;
   }
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
-    if constexpr (K_ <= 6) {                                                               \
+    if constexpr (K_ <= 5) {                                                               \
       if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, q_off, st); \
     }                                                                                      \
     return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, q_off, st);                \
