@@ -119,10 +119,10 @@ def roofline_for_hidden_layer(B, dev):
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)
     achieved = flops / times[name] * 1e-12
     # HBM-side bytes per launch of the weight-gradient entry point: measured offline with
-    # rocprofv3 --pmc (separate passes; profiles/r01_e_traffic.json says how), valid for the
+    # rocprofv3 --pmc (separate passes; profiles/r01_i_traffic.json says how), valid for the
     # shape and method it was taken on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_e_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
     if B == 16384 and methods[2] == 5 and name == wname and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["traffic_bytes"]
