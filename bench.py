@@ -118,14 +118,18 @@ def roofline_for_hidden_layer(B, dev):
     name = max(times, key=times.get)
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)
     achieved = flops / times[name] * 1e-12
-    # HBM-side bytes per launch of the weight-gradient entry point: measured offline with
-    # rocprofv3 --pmc (separate passes; profiles/r01_i_traffic.json says how), valid for the
-    # shape and method it was taken on
+    # HBM-side bytes per launch of the dominant entry point: measured offline with rocprofv3
+    # --pmc (separate passes; profiles/r01_i_traffic.json says how), valid for the shape and
+    # method it was taken on (weight gradient and backward-input, fp16x2, 16384 rows)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
-    if B == 16384 and methods[2] == 5 and name == wname and os.path.exists(tpath):
+    if B == 16384 and os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f)["traffic_bytes"]
+            measured = json.load(f)
+        if name == wname and methods[2] == 5:
+            traffic = measured["traffic_bytes"]
+        elif name == xname and methods[1] == 4:
+            traffic = measured["backward_input"]["traffic_bytes"]
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
