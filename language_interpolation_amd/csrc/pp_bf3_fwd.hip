@@ -444,6 +444,11 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
   // PP_BF3_VARIANT=<rm><nt> overrides (tuning).
   int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
   int nt = sh.O > 128 ? 2 : 1;
+  // fp16x2, K >= 7, 64-out wave tiles (the W ping-pong variant with two wave groups): one
+  // instantiation (n = K = 7) gave intermittently wrong rows on the GPU, about one run in five
+  // of test_fp16x2_all_instantiations_large_batch; cause not found.  Those layers take the
+  // 32-out wave tiles (W ring), which never failed.
+  if (SC::kRanged && sh.K >= 7) nt = 1;
   if (const char* v = getenv("PP_BF3_VARIANT")) {
     const int code = atoi(v);
     if (code / 10 >= 1 && code / 10 <= 2 && code % 10 >= 1 && code % 10 <= 2) {
@@ -493,7 +498,9 @@ hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* 
 }
 
 // whole rows in one block: what the fused LayerNorm epilogue needs
-bool pp_h2_fwd_ln_supported(const PPShape& sh) { return pp_bf3_supported(sh) && sh.O <= 256; }
+bool pp_h2_fwd_ln_supported(const PPShape& sh) {
+  return pp_bf3_supported(sh) && sh.O <= (sh.K >= 7 ? 128 : 256);  // (see launch_fwd_split)
+}
 
 // fp16x2 forward layout only (header | P), absmax included: first half of pp_pack_weights
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh) {
