@@ -80,11 +80,11 @@ def roofline_for_hidden_layer(B, dev):
     y = torch.empty(B, O, device=dev)
     gx = torch.empty(B, I, device=dev)
     gw = torch.empty(I, K, O, device=dev)
-    nbytes = lib.pp_workspace_bytes(B, I, O, n, S, 0, 0)
+    nbytes = lib.pp_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    fbytes = lib.pp_forward_workspace_bytes(B, I, O, n, S, 0, 0)
+    fbytes = lib.pp_forward_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
     fws = torch.empty(max(fbytes, 16), dtype=torch.uint8, device=dev)
-    xbytes = lib.pp_backward_input_workspace_bytes(B, I, O, n, S, 0, 0)
+    xbytes = lib.pp_backward_input_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
     xws = torch.empty(max(xbytes, 16), dtype=torch.uint8, device=dev)
     nodes = spec.node_array()
     st = PF._stream(dev)
@@ -103,7 +103,7 @@ def roofline_for_hidden_layer(B, dev):
         lib.pp_backward_weight_f32(P(x), P(gy), P(gw), P(ws), nbytes, B, I, O, n, S, 0, 2.0, nodes,
                                    1.0, 0, st)
 
-    methods = [lib.pp_auto_method(p, B, I, O, n, S, 0) for p in range(3)]
+    methods = [lib.pp_auto_method(p, B, I, O, n, S, 0, 2.0) for p in range(3)]
     fname = {1: "pp_fwd_gather_kernel", 2: "pp_fwd_dense_kernel",
              3: "pp_fwd_bf3_kernel<bf16x3>(+pack)",
              4: "pp_fwd_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[0]]

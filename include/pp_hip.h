@@ -21,7 +21,9 @@
  *   - all data pointers are DEVICE pointers, fp32, contiguous row-major,
  *     16-byte aligned; the caller owns every buffer, the library allocates
  *     nothing and keeps no state between calls (safe from any host thread --
- *     autograd calls backward from its own engine thread).
+ *     autograd calls backward from its own engine thread; the only runtime
+ *     state touched is hipFuncSetAttribute on the launching device, set on
+ *     every call that needs it).
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
  *     stream-ordered; no call synchronises the device.
  *   - B rows (samples), I in_features, O out_features, n nodes per segment,
@@ -71,7 +73,9 @@ enum {
                          range, fp32 fix-up of tiles whose basis does not fit (fp32-level accuracy);
                          needs a workspace */
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
-  PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; no atomics on gw */
+  PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; float atomics only
+                          for buckets shared between segments (continuous layers) or spanning
+                          two reduce units */
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
   PP_BWD_W_FP16X2 = 5, /* same on fp16 MFMA, operands split 2-way, gy scaled per (512 rows, out) */
   PP_BWD_W_BF16X3 = 4, /* Phi^T x gy on bf16 MFMA, operands split 3-way (small K only) */
@@ -107,7 +111,8 @@ int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
 /* Same as pp_forward_f32 with caller-owned scratch (pp_forward_workspace_bytes; may be
  * NULL/0 for methods that need none).  PP_METHOD_AUTO may pick a workspace method
  * only through this entry point. */
-size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method);
+size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                  float length, int method);
 int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
                       void* workspace, size_t workspace_bytes, int B, int I, int O, int n, int S,
                       int discontinuous, float length, const float* nodes, float out_scale,
@@ -121,9 +126,9 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
  * (backward-input): the call then only reads it.  It must be rewritten whenever w_t
  * changes.  No reference counterpart (layout adaptor, like pp_transpose_w_f32). */
 #define PP_WS_PREPACKED 0x100
-size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous);
+size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous, float length);
 int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int I, int O, int n,
-                        int S, int discontinuous, void* stream);
+                        int S, int discontinuous, float length, void* stream);
 
 /* Backward w.r.t. the input (A4' of SURVEY.md 8(a)):
  * gx[b,i] = out_scale * (L/(x_max-x_min)) * sum_o gy[b,o] * sum_j l'_j(xi) * w_t[i, s*stride+j, o].
@@ -137,7 +142,7 @@ int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, flo
  * NULL/0 for methods that need none).  PP_METHOD_AUTO may pick a workspace method only
  * through this entry point. */
 size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
-                                         int method);
+                                         float length, int method);
 int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
                              void* workspace, size_t workspace_bytes, int B, int I, int O, int n,
                              int S, int discontinuous, float length, const float* nodes,
@@ -146,7 +151,8 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
 /* Bytes of scratch pp_backward_weight_f32 needs for `method` (0 for methods
  * that need none).  Scratch is caller-owned device memory, 16-byte aligned,
  * contents undefined on entry and exit. */
-size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method);
+size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, float length,
+                          int method);
 
 /* Backward w.r.t. the weights (A4'): gw_t[i,k,o] = out_scale * sum_{(b,j): s[b,i]*stride+j==k}
  * gy[b,o] * l_j(xi[b,i]); DENSE result in the kernel layout [I][K][O], every
@@ -171,7 +177,8 @@ int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* s
  * fp16x2 kernel on weights pre-split by pp_pack_weights_f32 (`packed`).
  * pp_forward_layer_norm_supported: 1 when this shape has the fused kernel (dense regime,
  * O <= 256) and it is what PP_METHOD_AUTO would run. */
-int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous);
+int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                    float length);
 int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float* rstd,
                               void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
                               int discontinuous, float length, const float* nodes, float out_scale,
@@ -211,8 +218,10 @@ int pp_selective_scan_bwd_f32(const float* u, const float* delta, const float* A
                               int b, int l, int d, int n, void* stream);
 
 /* Which method PP_METHOD_AUTO resolves to for a shape (for logs and tests).
- * pass: 0 forward, 1 backward-input, 2 backward-weight. */
-int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous);
+ * pass: 0 forward, 1 backward-input, 2 backward-weight.  `length` matters: the matrix-core
+ * kernels need a power-of-two length (and S) so that A1/A2's divisions stay exact; any other
+ * length (the reference accepts every input_scale, networks.py:386-425) takes the gather path. */
+int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous, float length);
 
 #ifdef __cplusplus
 }

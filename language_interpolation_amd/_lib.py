@@ -31,13 +31,13 @@ _P = c_void_p
 SIGNATURES = {
     "pp_version": (c_int, []),
     "pp_error_string": (ctypes.c_char_p, [c_int]),
-    "pp_auto_method": (c_int, [c_int] * 7),
+    "pp_auto_method": (c_int, [c_int] * 7 + [c_float]),
     "pp_segment_ids_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),
     "pp_forward_f32": (
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
     ),
-    "pp_forward_workspace_bytes": (c_size_t, [c_int] * 7),
+    "pp_forward_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_forward_ws_f32": (
         c_int,
         [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
@@ -47,21 +47,21 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
     ),
-    "pp_packed_weights_bytes": (c_size_t, [c_int] * 5),
-    "pp_pack_weights_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _P]),
-    "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 7),
+    "pp_packed_weights_bytes": (c_size_t, [c_int] * 5 + [c_float]),
+    "pp_pack_weights_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_input_ws_f32": (
         c_int,
         [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
          c_float, c_int, _P],
     ),
-    "pp_workspace_bytes": (c_size_t, [c_int] * 7),
+    "pp_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_weight_f32": (
         c_int,
         [_P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float,
          c_int, _P],
     ),
-    "pp_forward_layer_norm_supported": (c_int, [c_int] * 6),
+    "pp_forward_layer_norm_supported": (c_int, [c_int] * 6 + [c_float]),
     "pp_forward_layer_norm_f32": (
         c_int,
         [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,

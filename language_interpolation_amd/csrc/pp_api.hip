@@ -60,7 +60,7 @@ bool dense_preferred(const PPShape& sh) {
 
 extern "C" {
 
-int pp_version(void) { return 100; }
+int pp_version(void) { return 200; }
 
 const char* pp_error_string(int code) {
   switch (code) {
@@ -75,9 +75,9 @@ const char* pp_error_string(int code) {
   }
 }
 
-int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous) {
+int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous, float length) {
   PPShape sh;
-  int rc = make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f);
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f);
   if (rc != PP_OK) return rc;
   const bool dense = dense_preferred(sh);
   switch (pass) {
@@ -106,19 +106,19 @@ static size_t packed_weights_bytes(const PPShape& sh) {
   return pp_h2_fwd_packed_bytes(sh) + pp_h2_bwd_x_packed_bytes(sh);
 }
 
-size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous) {
+size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous, float length) {
   PPShape sh;
-  if (make_shape(sh, 256, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (make_shape(sh, 256, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (!pp_bf3_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return 0;
   return packed_weights_bytes(sh);
 }
 
 int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int I, int O, int n,
-                        int S, int discontinuous, void* stream) {
+                        int S, int discontinuous, float length, void* stream) {
   if (!w_t || !packed) return PP_ERR_NULL;
   if (!aligned16(w_t) || !aligned16(packed)) return PP_ERR_ALIGN;
   PPShape sh;
-  int rc = make_shape(sh, 256, I, O, n, S, discontinuous, 2.0f, 1.0f);
+  int rc = make_shape(sh, 256, I, O, n, S, discontinuous, length, 1.0f);
   if (rc != PP_OK) return rc;
   if (!pp_bf3_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
   if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
@@ -133,9 +133,10 @@ static int fwd_auto(const PPShape& sh, bool have_ws) {
   return PP_FWD_DENSE;
 }
 
-size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method) {
+size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                  float length, int method) {
   PPShape sh;
-  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (method == PP_METHOD_AUTO) method = fwd_auto(sh, true);
   if ((method == PP_FWD_BF16X3 || method == PP_FWD_FP16X2) && pp_bf3_supported(sh))
     return pp_bf3_fwd_workspace_bytes(sh);
@@ -196,9 +197,9 @@ static int bwd_x_auto(const PPShape& sh, bool have_ws) {
 }
 
 size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
-                                         int method) {
+                                         float length, int method) {
   PPShape sh;
-  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (method == PP_METHOD_AUTO) method = bwd_x_auto(sh, true);
   if ((method == PP_BWD_X_BF16X3 || method == PP_BWD_X_FP16X2) && pp_bf3_bwd_x_supported(sh))
     return pp_bf3_bwd_x_workspace_bytes(sh);
@@ -253,10 +254,11 @@ int pp_backward_input_f32(const float* x, const float* gy, const float* w_t, flo
                                   nodes, out_scale, method, stream);
 }
 
-size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, int method) {
+size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, float length,
+                          int method) {
   PPShape sh;
-  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
-  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous);
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
+  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous, length);
   if (method == PP_BWD_W_SORT) return pp_sort_supported(sh) ? pp_sort_workspace_bytes(sh) : 0;
   if (method == PP_BWD_W_DENSE)
     return pp_dense_supported(sh) ? pp_dense_bwd_weight_workspace_bytes(sh) : 0;
@@ -277,7 +279,7 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
   if (rc != PP_OK) return rc;
   BasisTab tab;
   make_basis(tab, n, length, nodes);
-  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous);
+  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous, length);
   hipStream_t st = (hipStream_t)stream;
   switch (method) {
     case PP_BWD_W_ATOMIC:
@@ -343,9 +345,10 @@ int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float*
                                  (hipStream_t)stream));
 }
 
-int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous) {
+int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                    float length) {
   PPShape sh;
-  if (make_shape(sh, B, I, O, n, S, discontinuous, 2.0f, 1.0f) != PP_OK) return 0;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   return pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && dense_preferred(sh) &&
          sh.B >= 256;
 }

@@ -169,8 +169,10 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
   auto produce = [&](int t, int buf, const float (&xv)[2]) {
     const int row = cbeg + 16 * t + 2 * rp;
     float pa[K], pb[K];
-    phi3<N, K>(xv[0], row < cend, sh, tab, dc, pa, SC::kRanged ? &lmax : nullptr);
-    phi3<N, K>(xv[1], row + 1 < cend, sh, tab, dc, pb, SC::kRanged ? &lmax : nullptr);
+    // (rows past the chunk: x = 0, so that they cannot trip the range check)
+    phi3<N, K>(row < cend ? xv[0] : 0.0f, row < cend, sh, tab, dc, pa, SC::kRanged ? &lmax : nullptr);
+    phi3<N, K>(row + 1 < cend ? xv[1] : 0.0f, row + 1 < cend, sh, tab, dc, pb,
+               SC::kRanged ? &lmax : nullptr);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       unsigned w[PL];
@@ -236,6 +238,11 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
       for (int nt = 0; nt < NT; ++nt) {
         const float2 nsc = gscale[(size_t)sb * Opad + ccol[nt]];
         const float f = nsc.x * csc[nt].y;  // new scale / old scale: a power of two
+        // blocks of rows whose gradients differ by more than 2^60: the rescaled accumulators
+        // could overflow where plain fp32 would not -> this tile takes the fp32 path below
+        const int de = (int)((__float_as_uint(nsc.x) >> 23) & 0xffu) -
+                       (int)((__float_as_uint(csc[nt].x) >> 23) & 0xffu);
+        if (de > 60 || de < -60) lmax = __builtin_inff();
         csc[nt] = nsc;
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -325,7 +332,9 @@ WPlan3 wplan3(const PPShape& sh) {
   p.ocols = (sh.O + 128 * p.nt - 1) / (128 * p.nt);
   const int tiles = ((sh.I + 31) / 32) * p.ocols;
   int target = 256;
+#ifdef PP_TUNING  // developer builds only
   if (const char* v = getenv("PP_BF3_BWDW_BLOCKS")) target = std::max(1, atoi(v));
+#endif
   int nchunk = std::max(1, target / tiles);
   const int max_chunks = std::max(1, sh.B / 128);  // >= 8 steps of 16 rows per block
   nchunk = std::min(nchunk, max_chunks);
@@ -346,14 +355,10 @@ hipError_t launch_bwd_w_bf3(const float* x, const float* gy, const void* ws, flo
                             const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
                             const WPlan3& p, float scale, hipStream_t st) {
   const size_t lds = (size_t)3 * SC::PL * K * 2 * 32 * 16;
-  if (lds > 48 * 1024) {
-    static bool once = false;  // per instantiation
-    if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_w_bf3_kernel<SC, N, K, NT>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      once = true;
-    }
+  if (lds > 48 * 1024) {  // per call: the attribute is per device, and setting it is cheap
+    hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_w_bf3_kernel<SC, N, K, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
   dim3 grid(p.nchunk, (sh.I + 31) / 32, p.ocols);
   const char* base = static_cast<const char*>(ws);

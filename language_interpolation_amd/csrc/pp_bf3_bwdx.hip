@@ -112,7 +112,10 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
       h2_scale(rmaxL[buf][prow], rs, inv);
       if (threadIdx.x < ROWS) {
         rscL[buf][prow] = make_float2(rs, inv);
-        rmaxL[buf ^ 1][prow] = 0u;  // consumed one chunk ago; next written after a barrier
+        // the next chunk starts from this running maximum (its slot was consumed one chunk
+        // ago and is next written after a barrier): a row's scale never grows from chunk to
+        // chunk, so the accumulator rescale factor below is <= 1 and cannot overflow
+        rmaxL[buf ^ 1][prow] = rmaxL[buf][prow];
       }
     }
 #pragma unroll
@@ -328,14 +331,10 @@ hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, flo
                             const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
                             unsigned q_off, hipStream_t st) {
   const size_t lds = (size_t)2 * SC::PL * kOC * 2 * 32 * RM * 16;
-  if (lds > 40 * 1024) {
-    static bool once = false;  // per instantiation
-    if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<SC, N, K, RM>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      once = true;
-    }
+  if (lds > 40 * 1024) {  // per call: the attribute is per device, and setting it is cheap
+    hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<SC, N, K, RM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
   const int vw = sh.O % 4 == 0 ? 4 : (sh.O % 2 == 0 ? 2 : 1);
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (ipad_of(sh) + 127) / 128);
@@ -369,10 +368,12 @@ hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, 
   if (!prepacked) pack_wo_split<SC>(wt, ws, q_off, sh, true, st);
   // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
   int rm = sh.B >= 4096 && sh.K <= 5 ? 2 : 1;  // K = 6 at 64 rows spills hundreds of registers
+#ifdef PP_TUNING  // developer builds only
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
     const int c = atoi(v);
     if ((c == 1 || c == 2) && (c == 1 || sh.K <= 6)) rm = c;
   }
+#endif
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
     if constexpr (K_ <= 5) {                                                               \

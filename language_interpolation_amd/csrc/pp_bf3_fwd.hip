@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
       float pa[K], pb[K];
-      phi3<N, K>(xv[rm][0], i0 < sh.I, sh, tab, dc, pa, SC::kRanged ? &lmax : nullptr);
-      phi3<N, K>(xv[rm][1], i0 + 1 < sh.I, sh, tab, dc, pb, SC::kRanged ? &lmax : nullptr);
+      // (padded inputs i >= I hold the next row's x: evaluate them at x = 0 so that they
+      // cannot trip the range check)
+      phi3<N, K>(i0 < sh.I ? xv[rm][0] : 0.0f, i0 < sh.I, sh, tab, dc, pa,
+                 SC::kRanged ? &lmax : nullptr);
+      phi3<N, K>(i0 + 1 < sh.I ? xv[rm][1] : 0.0f, i0 + 1 < sh.I, sh, tab, dc, pb,
+                 SC::kRanged ? &lmax : nullptr);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         unsigned w[PL];
@@ -200,10 +204,9 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   PP_TICK(1)
-  // (An earlier version ran the two groups in opposite orders -- basis first vs MFMAs first
-  // -- to interleave vector and matrix work on a SIMD; it bought ~3 % and gave intermittently
-  // wrong rows in one instantiation (N = K = 7, three steps per group), so both groups use
-  // the same order.)
+  // (Both groups run produce -> MFMA.  The wrong rows once blamed on running them in opposite
+  // orders were a packed-fp32 instruction of the SLP vectoriser misbehaving when two workgroups
+  // share a CU -- DESIGN.md 3c'; the library is built with -fno-slp-vectorize.)
   auto stepfn = [&](int t, auto par) {
     constexpr int P0 = decltype(par)::value;
     const int buf = t & 1;
@@ -402,14 +405,10 @@ hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y,
   const size_t red = G == 2 ? (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4 : 0;
   lds = std::max(lds, red + (size_t)(8 * G + 2) * 32 * RM * 4);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (lds > 48 * 1024) {
-    static bool once = false;  // per instantiation
-    if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      once = true;
-    }
+  if (lds > 48 * 1024) {  // per call: the attribute is per device, and setting it is cheap
+    hipError_t e = hipFuncSetAttribute((const void*)pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
   }
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 128 * NT - 1) / (128 * NT));
   if (rstd && grid.y != 1) return hipErrorInvalidValue;  // the fused norm needs whole rows
@@ -441,14 +440,9 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
   if (!prepacked) pack_w_split<SC>(wt, ws, sh, true, st);
   // variant: 64-row tiles once they fill the chip (K <= 6: two groups' basis buffers fit
   // LDS); waves of 32 outs when O <= 128 so all four column waves have work.
-  // PP_BF3_VARIANT=<rm><nt> overrides (tuning).
   int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
   int nt = sh.O > 128 ? 2 : 1;
-  // fp16x2, K >= 7, 64-out wave tiles (the W ping-pong variant with two wave groups): one
-  // instantiation (n = K = 7) gave intermittently wrong rows on the GPU, about one run in five
-  // of test_fp16x2_all_instantiations_large_batch; cause not found.  Those layers take the
-  // 32-out wave tiles (W ring), which never failed.
-  if (SC::kRanged && sh.K >= 7) nt = 1;
+#ifdef PP_TUNING  // developer builds only: PP_BF3_VARIANT=<rm><nt>
   if (const char* v = getenv("PP_BF3_VARIANT")) {
     const int code = atoi(v);
     if (code / 10 >= 1 && code / 10 <= 2 && code % 10 >= 1 && code % 10 <= 2) {
@@ -456,6 +450,7 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
       nt = code % 10;
     }
   }
+#endif
 #define X(N_, K_)                                                                              \
   if (sh.n == N_ && sh.K == K_) {                                                              \
     hipError_t e = hipErrorInvalidValue;                                                       \
@@ -499,7 +494,7 @@ hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* 
 
 // whole rows in one block: what the fused LayerNorm epilogue needs
 bool pp_h2_fwd_ln_supported(const PPShape& sh) {
-  return pp_bf3_supported(sh) && sh.O <= (sh.K >= 7 ? 128 : 256);  // (see launch_fwd_split)
+  return pp_bf3_supported(sh) && sh.O <= 256;
 }
 
 // fp16x2 forward layout only (header | P), absmax included: first half of pp_pack_weights

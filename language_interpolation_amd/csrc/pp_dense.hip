@@ -665,9 +665,15 @@ bool is_exact(const PPShape& sh) {
 
 int vec_width(int O) { return O % 4 == 0 ? 4 : (O % 2 == 0 ? 2 : 1); }
 
+// tuning overrides exist in developer builds (-DPP_TUNING) only
 int env_int(const char* name, int dflt) {
+#ifdef PP_TUNING
   const char* v = std::getenv(name);
   return v ? std::atoi(v) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 
 struct WeightPlan {
@@ -776,13 +782,10 @@ hipError_t pp_launch_bwd_input_dense(const float* x, const float* gy, const floa
 #define X(N_, K_)                                                                              \
   if (sh.n == N_ && sh.K == K_) {                                                              \
     const size_t lds = 2 * (size_t)K_ * 32 * kWStride * sizeof(float);                         \
-    if (lds > 48 * 1024) {                                                                     \
-      static bool once = false;                                                                \
-      if (!once) {                                                                             \
-        (void)hipFuncSetAttribute((const void*)pp_bwd_input_dense_kernel<N_, K_>,                    \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        once = true;                                                                           \
-      }                                                                                        \
+    if (lds > 48 * 1024) { /* per call: the attribute is per device */                         \
+      hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_input_dense_kernel<N_, K_>,       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                           \
     }                                                                                          \
     hipLaunchKernelGGL((pp_bwd_input_dense_kernel<N_, K_>), grid, dim3(256), lds, st, x, gy, wt, \
                        gx, sh, tab, dc, vw);                                                   \

@@ -97,17 +97,18 @@ def pack_weights(w_t, spec: LayerSpec, B: int):
         return None
     lib = _lib.load()
     I, K, O = w_t.shape
-    args = (B, I, O, spec.n, spec.segments, int(spec.discontinuous))
+    args = (B, I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length)
     if lib.pp_auto_method(0, *args) != _lib.FWD_FP16X2 or \
             lib.pp_auto_method(1, *args) != _lib.BWD_X_FP16X2:
         return None
-    nbytes = lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous))
+    nbytes = lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous),
+                                         spec.length)
     if not nbytes:
         return None
     packed = torch.empty(nbytes, device=w_t.device, dtype=torch.uint8)
     with torch.cuda.device(w_t.device):
         rc = lib.pp_pack_weights_f32(_ptr(w_t), _ptr(packed), nbytes, I, O, spec.n, spec.segments,
-                                     int(spec.discontinuous), _stream(w_t.device))
+                                     int(spec.discontinuous), spec.length, _stream(w_t.device))
     _lib.check(rc, "pp_pack_weights_f32")
     return packed
 
@@ -131,7 +132,7 @@ def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False, packed=None):
     else:
         method = _lib.FWD_METHODS[spec.fwd_method]
         nbytes = lib.pp_forward_workspace_bytes(B, I, O, spec.n, spec.segments,
-                                                int(spec.discontinuous), method)
+                                                int(spec.discontinuous), spec.length, method)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.pp_forward_ws_f32(
@@ -154,7 +155,8 @@ def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None):
     else:
         method = _lib.BWD_X_METHODS[spec.bwd_x_method]
         nbytes = lib.pp_backward_input_workspace_bytes(B, I, O, spec.n, spec.segments,
-                                                       int(spec.discontinuous), method)
+                                                       int(spec.discontinuous), spec.length,
+                                                       method)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.pp_backward_input_ws_f32(
@@ -174,7 +176,8 @@ def backward_weight_raw(x, gy, w_shape_t, spec: LayerSpec):
     if B == 0:
         return gw_t.zero_()
     method = _lib.BWD_W_METHODS[spec.bwd_w_method]
-    nbytes = lib.pp_workspace_bytes(B, I, O, spec.n, spec.segments, int(spec.discontinuous), method)
+    nbytes = lib.pp_workspace_bytes(B, I, O, spec.n, spec.segments, int(spec.discontinuous),
+                                    spec.length, method)
     ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
         rc = lib.pp_backward_weight_f32(
@@ -250,7 +253,7 @@ def layer_norm_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> boo
         return False
     O, I, _ = w.shape
     return bool(_lib.load().pp_forward_layer_norm_supported(
-        x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous)))
+        x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length))
 
 
 class PiecewisePolyLayerNormFunction(torch.autograd.Function):

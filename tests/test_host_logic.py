@@ -40,26 +40,36 @@ def test_argument_validation_without_a_gpu():
     assert lib.pp_forward_f32(misaligned, fake, fake, null, 4, 4, 4, 2, 2, 0, 2.0, null, 1.0, 0, null) == -3
     assert lib.pp_forward_f32(fake, fake, fake, null, 4, 4, 4, 2, 2, 0, 2.0, null, 1.0, 77, null) == -5
     # sort path needs a workspace
-    need = lib.pp_workspace_bytes(256, 16, 1000, 2, 128, 1, _lib.BWD_W_SORT)
+    need = lib.pp_workspace_bytes(256, 16, 1000, 2, 128, 1, 2.0, _lib.BWD_W_SORT)
     assert need > 0
     rc = lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 256, 16, 1000, 2, 128, 1, 2.0, null,
                                     1.0, _lib.BWD_W_SORT, null)
     assert rc == -4
-    assert lib.pp_workspace_bytes(256, 16, 1000, 2, 128, 1, _lib.BWD_W_ATOMIC) == 0
+    assert lib.pp_workspace_bytes(256, 16, 1000, 2, 128, 1, 2.0, _lib.BWD_W_ATOMIC) == 0
 
 
 def test_auto_method_selection():
     lib = _lib.load()
     # many segments -> gather / sort
-    assert lib.pp_auto_method(0, 1024, 16, 1000, 2, 128, 1) == _lib.FWD_GATHER
-    assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1) == _lib.BWD_W_SORT
-    assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1) == _lib.BWD_W_SORT
+    assert lib.pp_auto_method(0, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.BWD_W_SORT
+    assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1, 2.0) == _lib.BWD_W_SORT
     # few segments, wide layer -> expanded basis on the matrix cores (cfg2 hidden, cfg1 hidden)
     for p, want in ((0, _lib.FWD_FP16X2), (1, _lib.BWD_X_FP16X2), (2, _lib.BWD_W_DENSE)):
-        assert lib.pp_auto_method(p, 256, 250, 250, 3, 2, 0) == want
-        assert lib.pp_auto_method(p, 1000, 200, 200, 2, 2, 0) == want
+        assert lib.pp_auto_method(p, 256, 250, 250, 3, 2, 0, 2.0) == want
+        assert lib.pp_auto_method(p, 1000, 200, 200, 2, 2, 0, 2.0) == want
     # K = 9 (n=5, S=2) is beyond the dense kernels -> gather
-    assert lib.pp_auto_method(0, 35, 64, 64, 5, 2, 0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(0, 35, 64, 64, 5, 2, 0, 2.0) == _lib.FWD_GATHER
+    # a length that is not a power of two (the reference accepts any input_scale,
+    # networks.py:386-425) keeps the layer off the matrix-core kernels
+    assert lib.pp_auto_method(0, 256, 250, 250, 3, 2, 0, 3.0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(1, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_X_GATHER
+    assert lib.pp_auto_method(2, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_W_SORT
+    assert lib.pp_packed_weights_bytes(250, 250, 3, 2, 0, 3.0) == 0
+    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 3.0) == 0
+    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 1
+    # fp16x2 layers with K >= 7 keep the fused LayerNorm up to 256 outs
+    assert lib.pp_forward_layer_norm_supported(256, 64, 256, 4, 2, 0, 2.0) == 1
 
 
 def test_layer_constructor_and_parameter_layout():

@@ -1,0 +1,142 @@
+"""Regression tests for faults found in round 2 (DESIGN.md 3c', "wrong rows").
+
+The matrix-core kernels are deterministic: the same inputs give bitwise-identical outputs.  The
+round-1 "intermittent wrong rows" were a packed-fp32 instruction (put there by the SLP
+vectoriser) that returned 0 in 16 lanes whenever two workgroups shared a CU -- about a third of
+the workgroups of a launch that fills the chip twice, and a different third on every launch.
+Launching every instantiation at that occupancy several times and demanding identical bits is
+the sharpest detector for that class of fault; a row-wise comparison against the plain-fp32
+gather kernels catches a fault that became repeatable.
+"""
+import pytest
+import torch
+
+from pp_testlib import TOL, make_inputs, oracle_all, rel_err
+from test_parity_gpu import _COMBOS, check, hip_all
+
+pytestmark = pytest.mark.gpu
+
+
+def _pf():
+    from language_interpolation_amd import functional as PF
+    return PF
+
+
+def _rowwise(got, ref):
+    denom = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    return ((got - ref).abs() / denom).max().item()
+
+
+@pytest.mark.parametrize("combo", _COMBOS, ids=lambda c: f"n{c[0]}-S{c[1]}-{'d' if c[2] else 'c'}")
+@pytest.mark.parametrize("method", ["fp16x2", "bf16x3"])
+def test_matrix_core_kernels_repeatable_at_two_workgroups_per_cu(combo, method):
+    n, S, disc = combo
+    if not disc and n < 2:
+        pytest.skip("continuous layers need n >= 2")
+    PF = _pf()
+    # 64-row tiles x 2 workgroups x 256 CUs, and a ragged tail; I spans four 32-input groups
+    B, I, O = 2 * 256 * 64 + 8, 102, 160
+    gen = torch.Generator().manual_seed(100 + 10 * n + S)
+    K = PF.num_weights(n, S, disc)
+    x = (torch.randn(B, I, generator=gen) * 0.8).cuda()    # |x| < ~4: inside fp16's basis range
+    gy = (torch.randn(B, O, generator=gen) / O).cuda()
+    w_t = ((torch.rand(I, K, O, generator=gen) * 2 - 1) / I).cuda()
+    spec = PF.make_spec(n, S, disc, fwd_method=method, bwd_x_method=method, bwd_w_method=method,
+                        in_features=I)
+    plain = PF.make_spec(n, S, disc, fwd_method="gather", bwd_x_method="gather",
+                         bwd_w_method="sort", in_features=I)
+    y0 = gx0 = gw0 = None
+    for rep in range(3):
+        y, _ = PF.forward_raw(x, w_t, spec)
+        gx = PF.backward_input_raw(x, gy, w_t, spec)
+        gw = PF.backward_weight_raw(x, gy, tuple(w_t.shape), spec)
+        if rep == 0:
+            y0, gx0, gw0 = y, gx, gw
+            continue
+        for name, a, b in (("y", y, y0), ("gx", gx, gx0), ("gw", gw, gw0)):
+            if not torch.equal(a, b):
+                d = (a != b).nonzero()
+                raise AssertionError(
+                    f"{method} {name}: run {rep} differs from run 0 in {len(d)} entries, first at "
+                    f"{d[0].tolist()} (rows {sorted(set(d[:, 0].tolist()))[:8]})")
+    yp, _ = PF.forward_raw(x, w_t, plain)
+    gxp = PF.backward_input_raw(x, gy, w_t, plain)
+    # (both sides are fp32-accurate kernels with different summation orders; high-order
+    # derivative bases cancel heavily, hence 1e-4 -- the fault this guards against is O(1))
+    assert _rowwise(y0, yp) <= 1e-4, "forward vs gather kernel, row-wise"
+    if n > 1:
+        assert _rowwise(gx0, gxp) <= 1e-4, "backward-input vs gather kernel, row-wise"
+    gwp = PF.backward_weight_raw(x, gy, tuple(w_t.shape), plain)
+    # per (input, weight index) row of gw_t[I, K, O]
+    assert _rowwise(gw0.reshape(I * K, O), gwp.reshape(I * K, O)) <= 2e-4, "weight gradient rows"
+
+
+@pytest.mark.parametrize("combo", [(3, 2, False), (7, 1, True), (8, 1, True), (4, 2, False)],
+                         ids=lambda c: f"n{c[0]}-S{c[1]}-{'d' if c[2] else 'c'}")
+def test_bf16x3_wide_wave_tiles_large_batch(combo):
+    """bf16x3 with K >= 5 and O > 128 (64-out wave tiles, W ping-pong): the variant the round-1
+    dispatch rule steered fp16x2 away from, against the oracle."""
+    n, S, disc = combo
+    B, I, O = 8200, 70, 160
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=40 + n)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    check(hip_all(x, w, gy, n, S, disc, "bf16x3", "bf16x3", "bf16x3"), ref, "bf16x3 wide")
+
+
+def test_non_power_of_two_length_takes_the_gather_path_through_the_module():
+    """a dense-regime shape with scale=3.0 (the reference accepts any input_scale,
+    networks.py:386-425) must not pick the matrix-core kernels, whose exact coordinate
+    arithmetic needs a power-of-two length."""
+    import language_interpolation_amd as L
+    from language_interpolation_amd import _lib
+    from oracle import pp_oracle as po
+    lib = _lib.load()
+    assert lib.pp_auto_method(0, 512, 64, 64, 3, 2, 0, 3.0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(2, 512, 64, 64, 3, 2, 0, 3.0) == _lib.BWD_W_SORT
+    assert lib.pp_packed_weights_bytes(64, 64, 3, 2, 0, 3.0) == 0
+    assert lib.pp_packed_weights_bytes(64, 64, 3, 2, 0, 4.0) > 0
+    torch.manual_seed(3)
+    B, I, O, n, S = 512, 64, 64, 3, 2
+    for length in (3.0, 4.0):
+        layer = L.high_order_fc_layers("continuous", n=n, in_features=I, out_features=O,
+                                       segments=S, scale=length, device="cuda")
+        x = torch.randn(B, I)
+        gy = torch.randn(B, O) / O
+        xg = x.cuda().requires_grad_(True)
+        y = layer(xg)
+        y.backward(gy.cuda())
+        ref = po.piecewise_fwd_bwd(x, layer.w.detach().cpu().contiguous(), gy, n, S, False,
+                                   precision="f64", length=length)
+        assert rel_err(y.detach(), ref["y"]) <= TOL, length
+        assert rel_err(xg.grad, ref["gx"]) <= TOL, length
+        assert rel_err(layer.w.grad, ref["gw"]) <= TOL, length
+        # the LayerNorm-fused entry is offered only where the matrix-core kernel runs
+        from language_interpolation_amd import functional as PF
+        assert PF.layer_norm_fusable(xg.detach(), layer.w, layer._spec) == (length == 4.0)
+
+
+def test_fp16x2_extreme_gradient_scales_stay_finite():
+    """gradient blocks 1e-35 / 1 / 1e30 apart.  Weight gradient: a tile whose row
+    blocks differ by more than 2^60 takes the fp32 path.  Input gradient: a row's scale is a
+    running maximum over its out chunks, so the accumulator rescale never exceeds 1."""
+    PF = _pf()
+    n, S, disc = 3, 2, False
+    x, w, gy = make_inputs(2048 + 40, 96, 250, n, S, disc, "normal", seed=50)
+    gy[:512] *= 1e-35
+    gy[1024:1536] *= 1e30
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc, "dense", "dense", "fp16x2")
+    assert torch.isfinite(got["gw"]).all()
+    rr, gg = ref["gw"], got["gw"]
+    denom = rr.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-38)
+    assert ((gg - rr).abs() / denom).max().item() <= TOL
+    # input gradient: out chunks of very different size, largest first / last / in the middle
+    x, w, gy = make_inputs(300, 64, 600, 2, 2, False, "normal", seed=51)
+    for big in (slice(0, 128), slice(256, 384), slice(512, 600)):
+        g2 = gy * 1e-30
+        g2[:, big] = gy[:, big] * 1e30
+        g2[::3] = gy[::3]          # and rows of ordinary size in between
+        ref = oracle_all(x, w, g2, 2, 2, False)
+        got = hip_all(x, w, g2, 2, 2, False, "dense", "fp16x2", "dense")
+        assert torch.isfinite(got["gx"]).all()
+        assert _rowwise(got["gx"].double(), ref["gx"].double()) <= TOL, big

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   float *x, *g, *w, *gx; void* ws = nullptr;
   (void)hipMalloc(&x, hx.size() * 4); (void)hipMalloc(&g, hg.size() * 4);
   (void)hipMalloc(&w, hw.size() * 4); (void)hipMalloc(&gx, hx.size() * 4);
-  size_t wsb = pp_backward_input_workspace_bytes(B, I, O, n, S, 0, method);
+  size_t wsb = pp_backward_input_workspace_bytes(B, I, O, n, S, 0, 2.0f, method);
   if (wsb) (void)hipMalloc(&ws, wsb);
   (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(g, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   (void)hipMalloc(&x, hx.size() * 4);
   (void)hipMalloc(&w, hw.size() * 4);
   (void)hipMalloc(&y, (size_t)B * O * 4);
-  size_t wsb = pp_forward_workspace_bytes(B, I, O, n, S, disc, method);
+  size_t wsb = pp_forward_workspace_bytes(B, I, O, n, S, disc, 2.0f, method);
   if (wsb) (void)hipMalloc(&ws, wsb);
   (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);

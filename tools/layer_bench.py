@@ -91,7 +91,7 @@ def main():
                     continue
                 by = 4 * (B * I + B * O + W)
                 rows.append((f"bwd_w/{m}", t, by, 2 * B * I * O * n))
-            auto = [lib.pp_auto_method(p, B, I, O, n, S, int(disc)) for p in range(3)]
+            auto = [lib.pp_auto_method(p, B, I, O, n, S, int(disc), 2.0) for p in range(3)]
             print(f"== {name} B={B} (disc={int(disc)} n={n} {I}->{O} S={S} K={K}) auto={auto}")
             for what, t, by, fl in rows:
                 print(f"   {what:14s} {t:10.1f} us  {by / t * 1e-3:9.1f} GB/s  "
