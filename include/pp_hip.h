@@ -59,7 +59,8 @@ enum {
   PP_ERR_ALIGN = -3,     /* a pointer is not 16-byte aligned */
   PP_ERR_WORKSPACE = -4, /* workspace missing or smaller than pp_workspace_bytes() */
   PP_ERR_METHOD = -5,    /* unknown / inapplicable method id */
-  PP_ERR_RANGE = -6      /* index arithmetic would overflow int32 */
+  PP_ERR_RANGE = -6,     /* index arithmetic would overflow int32 */
+  PP_ERR_NOALLOC_SIZE = -7 /* pp_forward_noalloc_f32: the shape needs more than PP_NOALLOC_SCRATCH_BYTES */
 };
 
 /* method ids */
@@ -117,6 +118,21 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
                       void* workspace, size_t workspace_bytes, int B, int I, int O, int n, int S,
                       int discontinuous, float length, const float* nodes, float out_scale,
                       int method, void* stream);
+
+/* Forward for callers that cannot allocate device memory or hand over a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): pp_forward_ws_f32
+ * with the scratch taken from a fixed array inside the library (PP_NOALLOC_SCRATCH_BYTES per
+ * GPU the library runs on, held until the process ends).  It has no counterpart in the
+ * reference.  Same arguments and results as pp_forward_f32 / pp_forward_ws_f32 (bit-identical
+ * to the latter); PP_METHOD_AUTO may pick the workspace methods.  Shapes whose method needs
+ * more scratch than that return PP_ERR_NOALLOC_SIZE (pp_forward_workspace_bytes tells; a method
+ * without scratch, e.g. PP_FWD_GATHER, always fits).  Allocates nothing, frees nothing.  Every
+ * call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race -- serialise them or use pp_forward_ws_f32. */
+#define PP_NOALLOC_SCRATCH_BYTES (8u << 20)
+int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
+                           int O, int n, int S, int discontinuous, float length, const float* nodes,
+                           float out_scale, int method, void* stream);
 
 /* Pre-split weights for the fp16x2 kernels: one pass per weight UPDATE instead of one inside
  * every forward and backward-input call.  pp_pack_weights_f32 writes both kernels' layouts

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpphip.so")
 
 PP_MAX_N = 8
+NOALLOC_SCRATCH_BYTES = 8 << 20
 
 # method ids (include/pp_hip.h)
 METHOD_AUTO = 0
@@ -34,6 +35,10 @@ SIGNATURES = {
     "pp_auto_method": (c_int, [c_int] * 7 + [c_float]),
     "pp_segment_ids_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P]),
     "pp_forward_f32": (
+        c_int,
+        [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
+    ),
+    "pp_forward_noalloc_f32": (
         c_int,
         [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, c_int, _P],
     ),

@@ -3,8 +3,14 @@
 // synchronisation, no global state.
 #include <cmath>
 #include <cstdint>
+#include <mutex>
 
 #include "pp_internal.h"
+
+// Scratch of the allocation-free entry point (pp_forward_noalloc_f32): lives in the code
+// object, one copy per GPU the library runs on, held until the process ends.  Host code must
+// not use this name as an address -- it is resolved per device with hipGetSymbolAddress below.
+static __device__ __align__(256) unsigned char scratch[PP_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -50,6 +56,29 @@ void make_basis(BasisTab& tab, int n, float length, const float* nodes) {
 
 int hip_rc(hipError_t e) { return e == hipSuccess ? PP_OK : (int)e; }
 
+// Device address of `scratch` on the current device, resolved on the first call per device
+// (each GPU holds its own copy at its own address).
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+hipError_t scratch_on_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return hipSuccess;
+}
+
 // K small enough that the expanded basis Phi[B, I*K] is "genuinely dense"
 // (n/K nonzero per input) and the contraction wide enough to feed MFMA tiles.
 bool dense_preferred(const PPShape& sh) {
@@ -71,6 +100,10 @@ const char* pp_error_string(int code) {
     case PP_ERR_WORKSPACE: return "workspace missing or too small (see pp_workspace_bytes)";
     case PP_ERR_METHOD: return "unknown or inapplicable method for this shape";
     case PP_ERR_RANGE: return "index range exceeds int32";
+    case PP_ERR_NOALLOC_SIZE:
+      return "this shape and method need more scratch than the allocation-free entry point holds "
+             "(PP_NOALLOC_SCRATCH_BYTES); use pp_forward_ws_f32 with a caller-owned workspace, or a "
+             "method that needs none";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
@@ -188,6 +221,26 @@ int pp_forward_f32(const float* x, const float* w_t, float* y, int32_t* seg_out,
                    float out_scale, int method, void* stream) {
   return pp_forward_ws_f32(x, w_t, y, seg_out, nullptr, 0, B, I, O, n, S, discontinuous, length,
                            nodes, out_scale, method, stream);
+}
+
+int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
+                           int O, int n, int S, int discontinuous, float length, const float* nodes,
+                           float out_scale, int method, void* stream) {
+  if (method & PP_WS_PREPACKED) return PP_ERR_METHOD;  // that form reads a caller-owned buffer
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  const size_t need = pp_forward_workspace_bytes(B, I, O, n, S, discontinuous, length, method);
+  if (need > (size_t)PP_NOALLOC_SCRATCH_BYTES) return PP_ERR_NOALLOC_SIZE;
+  void* ptr = nullptr;
+  if (need) {
+    hipError_t e = scratch_on_current_device(&ptr);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  // Nothing in the forward scratch has to start at zero: the weight pack writes every byte it
+  // later reads (64 absmax partials + all pieces).  Calls that overlap on one GPU share it.
+  return pp_forward_ws_f32(x, w_t, y, seg_out, ptr, need ? (size_t)PP_NOALLOC_SCRATCH_BYTES : 0, B, I,
+                           O, n, S, discontinuous, length, nodes, out_scale, method, stream);
 }
 
 static int bwd_x_auto(const PPShape& sh, bool have_ws) {
