@@ -73,6 +73,9 @@ enum {
   PP_FWD_FP16X2 = 4,  /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor into fp16's
                          range, fp32 fix-up of tiles whose basis does not fit (fp32-level accuracy);
                          needs a workspace */
+  PP_FWD_SLAB = 5,    /* many segments, few inputs, large batch (the character-grid input layers):
+                         the weight slab of one input staged in LDS by LDS-DMA, rows gathered from
+                         there; PP_METHOD_AUTO picks it where it applies, else PP_ERR_METHOD */
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; float atomics only
                           for buckets shared between segments (continuous layers) or spanning

@@ -115,7 +115,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   const bool dense = dense_preferred(sh);
   switch (pass) {
     case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_FP16X2 : PP_FWD_DENSE)
-                         : PP_FWD_GATHER;
+                         : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
     case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
                          : PP_BWD_X_GATHER;
     case 2:
@@ -161,7 +161,7 @@ int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int
 }
 
 static int fwd_auto(const PPShape& sh, bool have_ws) {
-  if (!dense_preferred(sh)) return PP_FWD_GATHER;
+  if (!dense_preferred(sh)) return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
   if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_FP16X2;
   return PP_FWD_DENSE;
 }
@@ -201,6 +201,10 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
   }
   hipStream_t st = (hipStream_t)stream;
   if (method == PP_FWD_GATHER) return hip_rc(pp_launch_fwd_gather(x, w_t, y, seg_out, sh, tab, st));
+  if (method == PP_FWD_SLAB) {
+    if (!pp_slab_fwd_supported(sh)) return PP_ERR_METHOD;
+    return hip_rc(pp_launch_fwd_slab(x, w_t, y, seg_out, sh, tab, st));
+  }
   if (method == PP_FWD_DENSE) {
     if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_fwd_dense(x, w_t, y, seg_out, sh, tab, st));

@@ -28,6 +28,12 @@ hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* g
                                        const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
 
+// ---- LDS-staged slab path for many-segment layers with few inputs (pp_slab.hip) ----
+bool pp_slab_fwd_supported(const PPShape& sh);  // the kernel can run this shape
+bool pp_slab_fwd_preferred(const PPShape& sh);  // ... and measured faster than the gather kernel
+hipError_t pp_launch_fwd_slab(const float* x, const float* wt, float* y, int32_t* seg,
+                              const PPShape& sh, const BasisTab& tab, hipStream_t st);
+
 // ---- sort + segmented reduce path (pp_sort.hip) ----
 size_t pp_sort_workspace_bytes(const PPShape& sh);
 bool pp_sort_supported(const PPShape& sh);

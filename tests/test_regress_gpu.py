@@ -140,3 +140,44 @@ def test_fp16x2_extreme_gradient_scales_stay_finite():
         got = hip_all(x, w, g2, 2, 2, False, "dense", "fp16x2", "dense")
         assert torch.isfinite(got["gx"]).all()
         assert _rowwise(got["gx"].double(), ref["gx"].double()) <= TOL, big
+
+
+# (disc, n, S, I, O, B, dist): shapes the LDS-slab forward serves (many segments, few inputs,
+# large batch) -- 16-byte and 4-byte LDS-DMA, one and two floats per lane, ragged tiles
+SLAB_CASES = [
+    (True, 2, 128, 16, 1000, 4096 + 3, "char"),     # cfg4 input layer: K = 256, V = 1, 16 waves
+    (False, 2, 128, 16, 250, 16384, "char"),        # cfg2 input layer: rows not 16-byte aligned
+    (False, 2, 128, 16, 200, 8192 + 77, "char"),    # cfg1 input layer
+    (True, 1, 128, 16, 1000, 4096, "uniform"),      # n = 1
+    (False, 3, 64, 12, 520, 6000, "edges"),         # n = 3, boundary values, ragged out chunk
+    (True, 4, 32, 9, 516, 5000, "normal"),          # n = 4, out-of-range inputs
+]
+
+
+@pytest.mark.parametrize("case", SLAB_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_slab_forward_matches_oracle_and_gather(case):
+    from language_interpolation_amd import _lib
+    disc, n, S, I, O, B, dist = case
+    lib = _lib.load()
+    # PP_METHOD_AUTO takes the slab only where it measured faster (large tables, large batch)
+    K = n * S if disc else (n - 1) * S + 1
+    big = B >= 4096 and K >= 192 and I * K * O * 4 >= (8 << 20)
+    want = _lib.FWD_SLAB if big else _lib.FWD_GATHER
+    assert lib.pp_auto_method(0, B, I, O, n, S, int(disc), 2.0) == want, "planner"
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=70 + n)
+    xd = x.cuda()
+    w_t = w.cuda().permute(1, 2, 0).contiguous()
+    y, seg = PF.forward_raw(xd, w_t, PF.make_spec(n, S, disc, fwd_method="slab", in_features=I),
+                            want_seg=True)
+    yg, segg = PF.forward_raw(xd, w_t, PF.make_spec(n, S, disc, fwd_method="gather", in_features=I),
+                              want_seg=True)
+    assert torch.equal(seg, segg)
+    # same expressions, same order of the sum over inputs: identical bits to the gather kernel
+    assert torch.equal(y, yg)
+    ya, _ = PF.forward_raw(xd, w_t, PF.make_spec(n, S, disc, in_features=I))
+    assert torch.equal(ya, y)
+    rows = slice(0, 1500)   # the oracle materialises [B, I, O, n] in fp64: a slice of the rows
+    ref = oracle_all(x[rows], w, gy[rows], n, S, disc)
+    assert torch.equal(seg[rows].cpu().long(), ref["seg"].long())
+    assert rel_err(y[rows].cpu(), ref["y"]) <= TOL

@@ -65,7 +65,7 @@ def main():
             w_t = ((torch.rand(I, K, O, generator=gen) * 2 - 1) / I).to(dev)
             gy = (torch.randn(B, O, generator=gen) / O).to(dev)
             rows = []
-            for m in ("gather", "dense", "bf16x3", "fp16x2"):
+            for m in ("gather", "slab", "dense", "bf16x3", "fp16x2"):
                 spec = PF.make_spec(n, S, disc, fwd_method=m)
                 try:
                     t = time_fn(lambda: PF.forward_raw(x, w_t, spec), args.iters)
