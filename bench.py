@@ -62,29 +62,28 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds
 
 
-def roofline_for_hidden_layer(B, dev):
-    """Times the three kernels of one hidden layer (continuous n=3 250->250 S=2) and
-    reports the roofline of the one that takes longest."""
+def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=20):
+    """Seconds per launch of the three entry points of one layer (auto methods, preallocated
+    outputs and workspaces: the timed region is exactly the library's launches)."""
     from language_interpolation_amd import _lib
     from language_interpolation_amd import functional as PF
 
-    n, S, I, O = 3, 2, 250, 250
-    K = PF.num_weights(n, S, False)
+    K = PF.num_weights(n, S, disc)
     gen = torch.Generator().manual_seed(1)
-    x = torch.randn(B, I, generator=gen).to(dev)
+    x = (char_batch(B, I, gen) if dist_kind == "char" else torch.randn(B, I, generator=gen)).to(dev)
     w_t = ((torch.rand(I, K, O, generator=gen) * 2 - 1) / I).to(dev)
     gy = (torch.randn(B, O, generator=gen) / O).to(dev)
-    spec = PF.make_spec(n, S, False)
-    # preallocate outputs/workspace so the timed region is exactly the library's launches
+    spec = PF.make_spec(n, S, disc)
     lib = _lib.load()
+    d = int(disc)
     y = torch.empty(B, O, device=dev)
     gx = torch.empty(B, I, device=dev)
     gw = torch.empty(I, K, O, device=dev)
-    nbytes = lib.pp_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
+    nbytes = lib.pp_workspace_bytes(B, I, O, n, S, d, 2.0, 0)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    fbytes = lib.pp_forward_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
+    fbytes = lib.pp_forward_workspace_bytes(B, I, O, n, S, d, 2.0, 0)
     fws = torch.empty(max(fbytes, 16), dtype=torch.uint8, device=dev)
-    xbytes = lib.pp_backward_input_workspace_bytes(B, I, O, n, S, 0, 2.0, 0)
+    xbytes = lib.pp_backward_input_workspace_bytes(B, I, O, n, S, d, 2.0, 0)
     xws = torch.empty(max(xbytes, 16), dtype=torch.uint8, device=dev)
     nodes = spec.node_array()
     st = PF._stream(dev)
@@ -92,21 +91,32 @@ def roofline_for_hidden_layer(B, dev):
 
     # the same entry points, methods (auto) and workspaces the module's autograd function uses
     def fwd():
-        lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(fws), fbytes, B, I, O, n, S, 0, 2.0,
+        lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(fws), fbytes, B, I, O, n, S, d, 2.0,
                               nodes, 1.0, 0, st)
 
     def bwd_x():
-        lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(xws), xbytes, B, I, O, n, S, 0,
+        lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(xws), xbytes, B, I, O, n, S, d,
                                      2.0, nodes, 1.0, 0, st)
 
     def bwd_w():
-        lib.pp_backward_weight_f32(P(x), P(gy), P(gw), P(ws), nbytes, B, I, O, n, S, 0, 2.0, nodes,
+        lib.pp_backward_weight_f32(P(x), P(gy), P(gw), P(ws), nbytes, B, I, O, n, S, d, 2.0, nodes,
                                    1.0, 0, st)
 
-    methods = [lib.pp_auto_method(p, B, I, O, n, S, 0, 2.0) for p in range(3)]
+    methods = [lib.pp_auto_method(p, B, I, O, n, S, d, 2.0) for p in range(3)]
+    times = {"fwd": time_kernel(fwd, iters), "bwd_w": time_kernel(bwd_w, iters)}
+    if not first:
+        times["bwd_x"] = time_kernel(bwd_x, iters)
+    return times, methods, K
+
+
+def roofline_for_hidden_layer(B, dev):
+    """Times the three kernels of one hidden layer (continuous n=3 250->250 S=2) and
+    reports the roofline of the one that takes longest."""
+    n, S, I, O = 3, 2, 250, 250
+    t, methods, K = time_layer(B, False, n, S, I, O, dev)
     fname = {1: "pp_fwd_gather_kernel", 2: "pp_fwd_dense_kernel",
              3: "pp_fwd_bf3_kernel<bf16x3>(+pack)",
-             4: "pp_fwd_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[0]]
+             4: "pp_fwd_bf3_kernel<fp16x2>(+absmax,+pack)", 5: "pp_fwd_slab_kernel"}[methods[0]]
     xname = {1: "pp_bwd_input_gather_kernel", 2: "pp_bwd_input_dense_kernel",
              3: "pp_bwd_x_bf3_kernel<bf16x3>(+pack)",
              4: "pp_bwd_x_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[1]]
@@ -114,15 +124,17 @@ def roofline_for_hidden_layer(B, dev):
              3: "pp_bwd_weight_dense_kernel(+reduce)",
              4: "pp_bwd_w_bf3_kernel<bf16x3>(+pack,+reduce)",
              5: "pp_bwd_w_bf3_kernel<fp16x2>(+pack,+reduce)"}[methods[2]]
-    times = {fname: time_kernel(fwd), xname: time_kernel(bwd_x), wname: time_kernel(bwd_w)}
+    times = {fname: t["fwd"], xname: t["bwd_x"], wname: t["bwd_w"]}
     name = max(times, key=times.get)
     flops = 2.0 * B * I * O * n  # algorithmic flops of one pass (6*B*I*O*n for three)
     achieved = flops / times[name] * 1e-12
     # HBM-side bytes per launch of the dominant entry point: measured offline with rocprofv3
-    # --pmc (separate passes; profiles/r01_i_traffic.json says how), valid for the shape and
+    # --pmc (separate passes; profiles/*_traffic.json says how), valid for the shape and
     # method it was taken on (weight gradient and backward-input, fp16x2, 16384 rows)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
     if B == 16384 and os.path.exists(tpath):
         with open(tpath) as f:
             measured = json.load(f)
@@ -137,7 +149,33 @@ def roofline_for_hidden_layer(B, dev):
         "algorithmic_flops_per_launch": flops,
         "launch_us": {k: round(v * 1e6, 2) for k, v in times.items()},
         "auto_methods": methods,
+        "arith": "fp16 MFMA on 2-way split fp32 operands (3 cross terms, ~22 significant bits), "
+                 "fp32 accumulate; `peak` is the fp32 matrix peak the fp32 contract is priced "
+                 "against -- the kernel issues 5x the algorithmic flops as fp16 MFMAs "
+                 "(3 cross terms x K/n = 5/3 dense padding)",
     }
+
+
+def roofline_hbm(B, dev):
+    """The HBM-bound layers of BASELINE (many segments: SURVEY.md 8d rows 'cfg3 hidden' and
+    'cfg4 input'), timed live per entry point at the bench batch and at the reference batch:
+    algorithmic bytes (every operand touched once per pass, dense gw) over the sum of the
+    entry-point times, as a fraction of 8 TB/s."""
+    out = []
+    for name, disc, n, S, I, O, kind, first, ref_rows in (
+            ("cfg3 hidden (discontinuous n=1 200->200 S=150)", True, 1, 150, 200, 200, "normal", False, 1000),
+            ("cfg4 input (discontinuous n=2 16->1000 S=128)", True, 2, 128, 16, 1000, "char", True, 256)):
+        for rows in (B, ref_rows):
+            t, methods, K = time_layer(rows, disc, n, S, I, O, dev, kind, first, iters=10)
+            W = I * K * O
+            by = 4 * ((2 * rows * I + 2 * rows * O + 2 * W) if first
+                      else (3 * rows * I + 2 * rows * O + 3 * W))
+            tot = sum(t.values())
+            out.append({"layer": name, "rows": rows, "algorithmic_bytes": by,
+                        "launch_us": {k: round(v * 1e6, 2) for k, v in t.items()},
+                        "achieved": round(by / tot * 1e-9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(by / tot / (PEAK_HBM_GBS * 1e9), 4), "auto_methods": methods})
+    return out
 
 
 def step_bytes(B):
@@ -211,32 +249,80 @@ def train_chars_per_s(net, dev, B, steps, world, reducer, graph):
 
 
 def cpu_baseline(rows, steps=2):
-    """The CPU oracle in the reference formulation (gather [B,I,O,n] + einsum +
-    autograd), same network, on this box's host cores."""
+    """The CPU oracle on this box's host cores, same network: the reference formulation
+    (gather [B,I,O,n] + einsum + autograd) is `value`; the dense-expansion formulation
+    (Phi @ W^T matmul, SURVEY.md 8d "fairer CPU baseline") is reported beside it."""
     from oracle import pp_oracle as po
 
+    # the GPU box gives a one-GPU job 16 CPUs (os.cpu_count() there shows the whole machine)
     cores = max(1, min(16, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = po.OracleHighOrderMLP(normalization=po.OracleLazyLayerNormLastDim, **NET)
     gen = torch.Generator().manual_seed(0)
     x = char_batch(rows, 16, gen)
     gy = torch.randn(rows, 128, generator=gen) / 128
 
-    def step():
-        for p in net.parameters():
-            p.grad = None
-        y = net(x)
-        y.backward(gy)
+    def timed(net):
+        def step():
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            y.backward(gy)
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
         step()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} fwd+bwd steps of the same 5-layer net at {rows} rows "
-                      f"(torch CPU oracle, reference gather+einsum formulation), {dt:.3f} s/step"}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        return (time.perf_counter() - t0) / steps
+
+    torch.manual_seed(0)
+    dt = timed(po.OracleHighOrderMLP(normalization=po.OracleLazyLayerNormLastDim, **NET))
+    out = {"value": round(rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} fwd+bwd steps of the same 5-layer net at {rows} rows "
+                     f"(torch CPU oracle, reference gather+einsum formulation), {dt:.3f} s/step"}
+    try:
+        torch.manual_seed(0)
+        dt2 = timed(po.OracleHighOrderMLP(normalization=po.OracleLazyLayerNormLastDim,
+                                          formulation="dense", **NET))
+        out["dense_formulation"] = {"value": round(rows / dt2, 1), "unit": "samples/s",
+                                    "sample": f"same net and rows, expanded basis Phi @ W^T "
+                                              f"(oracle piecewise_forward_dense), {dt2:.3f} s/step"}
+    except TypeError:
+        pass
+    return out
+
+
+def spawn_ranks(n, argv, script=None, need_gpus=True):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script as child
+    processes (one rank per GPU, env as torch.distributed.run would set it) BEFORE this process
+    touches a GPU, pass rank 0's JSON line through, and fail loudly when a rank does."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if need_gpus and ndev < n:
+        print(f"bench.py: --gpus {n} asked but only {ndev} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}: fewer ranks finished than asked", file=sys.stderr)
+        return 1
+    sys.stdout.write(out0)
+    return 0
+
+
+def trace(msg):
+    if os.environ.get("PP_BENCH_TRACE"):
+        print(f"[rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -247,89 +333,136 @@ def main():
     ap.add_argument("--batch", type=int, default=16384, help="rows per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-layers", action="store_true", help="skip the roofline_hbm object")
     ap.add_argument("--cpu-rows", type=int, default=4096)
     ap.add_argument("--train-steps", type=int, default=20,
                     help="optimizer steps for the extra train chars/s figure (0 = skip)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks",
+                  file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # = RCCL
+        if dist.get_world_size() != world:
+            sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    trace("process group up")
 
     import language_interpolation_amd as L
-    from language_interpolation_amd.parallel import GradAllReducer, broadcast_parameters
+    from language_interpolation_amd.parallel import (GradAllReducer, GraphedGradAllReduce,
+                                                     broadcast_parameters)
 
     torch.manual_seed(0)
     net = L.HighOrderMLP(normalization=L.LazyLayerNormLastDim, device=dev, **NET)
     broadcast_parameters(net)
+    trace("parameters broadcast")
     B = args.batch
     gen = torch.Generator().manual_seed(100 + rank)
     x = char_batch(B, 16, gen).to(dev)
     gy = (torch.randn(B, 128, generator=gen) / 128).to(dev)
-    reducer = GradAllReducer(net.parameters()) if world > 1 else None
     params = list(net.parameters())
 
-    def step():
+    def compute():
         for p in params:
             p.grad = None
         y = net(x)
         y.backward(gy)
-        if reducer is not None:
-            reducer.finish()
 
-    use_graph = (world == 1) and not args.no_graph
+    def capture():
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                compute()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        # (thread_local: RCCL's watchdog thread may query events while this thread captures)
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+            compute()
+        return g
+
+    # N = 1 and N > 1 run the SAME captured compute graph per rank; with N > 1 the gradients
+    # (static buffers of the graph) are all-reduced after each replay, so weak-scaling
+    # efficiency compares graph with graph.  --no-graph: eager launches, and for N > 1 the
+    # per-parameter all-reduce started from autograd hooks so that it overlaps the backward.
     graph = None
-    if use_graph:
+    reducer = None
+    launch = "eager"
+    if not args.no_graph:
         try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            run = graph.replay
+            graph = capture()
+            launch = "hipgraph"
+            trace("graph captured")
         except Exception as e:  # capture refused: measure eager, and say so
             print(f"HIP graph capture failed ({type(e).__name__}: {e}); running eager",
                   file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-            run = step
+    if world > 1:
+        if graph is not None:
+            flat_reduce = GraphedGradAllReduce(params)
+            launch = "hipgraph + gradient all-reduce after each replay"
+
+            def run():
+                graph.replay()
+                flat_reduce()
+        else:
+            reducer = GradAllReducer(params)
+            launch = "eager, per-parameter all-reduce overlapped with backward"
+
+            def run():
+                compute()
+                reducer.finish()
     else:
-        run = step
+        run = graph.replay if graph is not None else compute
+
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     for _ in range(args.warmup):
         run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    trace("warm-up done")
+    dt = timed(run, args.steps)
+    trace("timed region done")
+    # the same step with eager launches (like-for-like figure for whoever compares modes)
+    eager_dt = None
+    if graph is not None and world == 1:
+        for _ in range(3):
+            compute()
+        eager_dt = timed(compute, args.steps)
 
     train_cps = None
     if args.train_steps > 0:
-        graph = graph  # (the captured graph keeps its own buffers; training runs eager)
+        if reducer is None and world > 1:
+            reducer = GradAllReducer(params)
         train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer, not args.no_graph)
 
     if rank == 0:
@@ -346,6 +479,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "arith": "fp32 in/out/accumulate; the segments=2 layers run fp16 MFMA on 2-way split "
+                     "operands (~22 significant bits, 1e-5 parity bar), the rest plain fp32",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: net=small width=250 n=3 hidden.layers=3 segments=2 "
@@ -353,19 +488,24 @@ def main():
                             "loss=<y,gy>, synthetic char batches",
                 "rows_per_gpu": B, "global_rows": world * B,
                 "parallelism": f"dp{world}" if world > 1 else "single",
-                "launch": "hipgraph" if graph is not None else "eager",
-                "grad_allreduce": "rccl, per-parameter, overlapped with backward" if world > 1 else None,
+                "launch": launch,
+                "grad_allreduce": ("rccl, " + launch) if world > 1 else None,
             },
         }
+        if eager_dt is not None:
+            out["eager_ms_per_step"] = round(eager_dt / args.steps * 1e3, 4)
         if train_cps is not None:
             out["train_chars_per_s"] = round(train_cps, 1)  # cross entropy + Adam (graph replay at N=1)
         hb = step_bytes(B)
         out["hbm_roofline"] = {"algorithmic_bytes_per_step": hb,
                                "achieved_GBs": round(hb / (dt / args.steps) * 1e-9, 1),
                                "frac_of_8TBs": round(hb / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4),
-                               "note": "segments=2 layers are MFMA-bound (SURVEY 8d): structurally low"}
+                               "note": "segments=2 layers are MFMA-bound (SURVEY 8d): structurally low; "
+                                       "the HBM-bound layers are in roofline_hbm"}
         if world == 1:
             out["roofline"] = roofline_for_hidden_layer(B, dev)
+            if not args.no_hbm_layers:
+                out["roofline_hbm"] = roofline_hbm(B, dev)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
         print(json.dumps(out))

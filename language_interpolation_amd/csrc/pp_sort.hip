@@ -1,4 +1,5 @@
-// Weight gradient by counting sort + segmented reduce (no atomics on gw).
+// Weight gradient by counting sort + segmented reduce (float atomics on gw only for buckets
+// that are shared between segments or span reduce units; see below).
 //
 //   gw_t[i,k,:] = sum over rows b whose active range covers k of  l_j(xi[b,i]) * gy[b,:]
 //

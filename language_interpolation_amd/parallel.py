@@ -99,6 +99,53 @@ class GradAllReducer:
         self._handles.clear()
 
 
+class GraphedGradAllReduce:
+    """Gradient exchange for a step whose forward+backward is replayed from a HIP graph: the
+    gradients then live in the graph's static buffers, so after each replay they are summed
+    over the ranks in place -- large ones on their physical storage, small ones through one
+    flat bucket -- and scaled by 1/world.  No hooks (nothing of autograd runs at replay)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
+                 small_numel: int = 65536, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.small_numel = small_numel
+        self.scale = (1.0 / self.world) if average else 1.0
+
+    def __call__(self) -> None:
+        if self.world <= 1:
+            return
+        small = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            if g.numel() < self.small_numel:
+                small.append(g)
+                continue
+            v = _physical_view(g)
+            back = None
+            if not v.is_contiguous():
+                back, v = g, g.contiguous()
+            # plain stream-ordered collectives: RCCL enqueues on its own stream and the
+            # current stream waits for it
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            if self.scale != 1.0:
+                v.mul_(self.scale)
+            if back is not None:
+                back.copy_(v)
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.scale != 1.0:
+                flat.mul_(self.scale)
+            off = 0
+            for g in small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None) -> None:
     """Make every replica start from rank `src`'s weights (what DDP does at wrap time)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) <= 1:

@@ -81,3 +81,65 @@ def test_grad_allreduce_matches_mean_of_per_rank_grads(tmp_path):
     for g, w_, st, p in zip(got["grads"], want, got["strides"], net.parameters()):
         assert torch.allclose(g, w_, rtol=1e-5, atol=1e-6)
         assert tuple(st) == tuple(p.stride())  # layout of the permuted leaf is kept
+
+
+def graphed_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from language_interpolation_amd.parallel import GraphedGradAllReduce, broadcast_parameters
+
+    torch.manual_seed(123 + rank)
+    net = nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
+    broadcast_parameters(net)
+    red = GraphedGradAllReduce(list(net.parameters()), small_numel=4096)
+    for _ in range(2):   # (what a graph replay leaves behind: fresh gradients in the same buffers)
+        for p in net.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        x, t = data(rank)
+        ((net(x) - t) ** 2).sum().backward()
+        red()
+    if rank == 0:
+        torch.save({"grads": [p.grad.clone() for p in net.parameters()],
+                    "strides": [p.grad.stride() for p in net.parameters()]}, out)
+    dist.destroy_process_group()
+
+
+def test_graphed_grad_allreduce_matches_mean_of_per_rank_grads(tmp_path):
+    """The exchange bench.py uses for N > 1 when the step is a HIP graph: in-place all-reduce of
+    the (static) gradient buffers after the replay."""
+    out = str(tmp_path / "g0.pt")
+    mp.spawn(graphed_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    torch.manual_seed(123)
+    net = nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(2):
+        for p in net.parameters():
+            p.grad = None
+        x, t = data(rank)
+        ((net(x) - t) ** 2).sum().backward()
+        for acc, p in zip(want, net.parameters()):
+            acc += p.grad / 2
+    for g, w_, st, p in zip(got["grads"], want, got["strides"], net.parameters()):
+        assert torch.allclose(g, w_, rtol=1e-5, atol=1e-6)
+        assert tuple(st) == tuple(p.stride())
+
+
+def test_bench_spawns_its_own_ranks_and_reports_failures(capsys):
+    """`python bench.py --gpus N` without torchrun: bench.spawn_ranks starts N ranks, passes
+    rank 0's JSON line through and returns non-zero when a rank does not finish."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_probe.py")
+    assert bench.spawn_ranks(2, [], script=probe, need_gpus=False) == 0
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line == {"n_ranks": 2, "sum": 3.0, "world_env": 2}
+    assert bench.spawn_ranks(2, ["1"], script=probe, need_gpus=False) == 1   # rank 1 exits 7
+    # asking for more GPUs than are visible fails before anything is started
+    if torch.cuda.device_count() < 64:
+        assert bench.spawn_ranks(64, [], need_gpus=True) == 2

@@ -181,3 +181,45 @@ def test_slab_forward_matches_oracle_and_gather(case):
     ref = oracle_all(x[rows], w, gy[rows], n, S, disc)
     assert torch.equal(seg[rows].cpu().long(), ref["seg"].long())
     assert rel_err(y[rows].cpu(), ref["y"]) <= TOL
+
+
+# BASELINE layer shapes at the bench batch (dense-regime layers) / a quarter of it (many-segment
+# layers: the fp64 oracle's expanded basis is B*I*K doubles)
+ROWWISE_SHAPES = [
+    ("cfg1 hidden", False, 2, 2, 200, 200, 16384, "normal"),
+    ("cfg2 hidden", False, 3, 2, 250, 250, 16384, "normal"),
+    ("cfg2 out", False, 3, 2, 250, 128, 16384, "normal"),
+    ("cfg5 in_proj", False, 3, 2, 256, 256, 15360, "normal"),
+    ("cfg2 input", False, 2, 128, 16, 250, 16384, "char"),
+    ("cfg3 hidden", True, 1, 150, 200, 200, 4096, "normal"),
+    ("cfg4 input", True, 2, 128, 16, 1000, 4096, "char"),
+]
+# The north_star bar (1e-5 of the tensor's largest entry) is asserted everywhere else; here the
+# same 1e-5 is demanded in the finer norms: row-wise for y / gx (each sample against its own
+# largest entry) and per (input, weight index) row for gw.  The fp16x2 kernels scale weights per
+# tensor and gy per (512 rows, column) / (row, 128 outs), so an entry far below its scale
+# block's maximum keeps fewer bits relative to ITSELF; relative to its row's maximum the
+# measured worst case over the BASELINE shapes is 1.7e-6 (profiles/r02_c_rowwise.txt).
+ROW_BAR = {"y": 1e-5, "gx": 1e-5, "gw": 1e-5}
+
+
+@pytest.mark.parametrize("shape", ROWWISE_SHAPES, ids=lambda s: s[0].replace(" ", "_"))
+def test_rowwise_error_of_auto_methods_on_baseline_shapes(shape):
+    name, disc, n, S, I, O, B, dist = shape
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=90)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    got = hip_all(x, w, gy, n, S, disc)
+    check(got, ref, name)
+    K = w.shape[2]
+    errs = {
+        "y": _rowwise(got["y"].double(), ref["y"].double()),
+        "gx": _rowwise(got["gx"].double(), ref["gx"].double()) if n > 1 else 0.0,
+        # [O, I, K] -> one row per (input, weight index)
+        "gw": _rowwise(got["gw"].double().permute(1, 2, 0).reshape(I * K, O),
+                       ref["gw"].double().permute(1, 2, 0).reshape(I * K, O)),
+    }
+    tens = {k: rel_err(got[k], ref[k]) for k in ("y", "gx", "gw") if ref[k].abs().max() > 0}
+    print(f"ROWWISE {name} B={B}: per-tensor {', '.join(f'{k} {v:.2e}' for k, v in tens.items())}"
+          f" | row-wise {', '.join(f'{k} {v:.2e}' for k, v in errs.items())}")
+    for k, v in errs.items():
+        assert v <= ROW_BAR[k], (name, k, v)

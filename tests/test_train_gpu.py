@@ -131,3 +131,31 @@ def test_graph_replayed_steps_match_eager_steps(overrides):
     for (le, ae), (lg, ag) in zip(*hists):
         assert abs(le - lg) <= 2e-3 * max(1.0, abs(le)), (hists[0], hists[1])
     assert hists[1][-1][0] < hists[1][0][0]
+
+
+def test_char_windows_and_sequences_are_exact_on_the_device():
+    """The device-side dataset path (text as one uint8 buffer in HBM, windows gathered on the
+    GPU): every window equals the reference construction (single_text_dataset.py:15-16, :102-123;
+    MambaMixin.collate_fn, lightning_datamodule.py:272-288) -- bit-exact, integer and float."""
+    from language_interpolation_amd import train as T
+    text = T.synthetic_text(5000, seed=3)
+    F = 16
+    data = T.CharWindows(text, F, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x, y, ids = data.sample(512, gen)
+    assert x.is_cuda and y.is_cuda and x.shape == (512, F) and y.shape == (512, 1)
+    codes = torch.tensor([ord(c) for c in text], dtype=torch.float32)
+    idc = ids.cpu()
+    win = torch.stack([codes[i:i + F] for i in idc.tolist()])
+    assert torch.equal(x.cpu(), (win - 64 + 0.5) / 64)
+    assert torch.equal(y.cpu().flatten().float(), codes[idc + F])
+    # first and last window
+    xb, yb, _ = data.batch(torch.tensor([0, len(data) - 1], device="cuda"))
+    assert torch.equal(xb[1].cpu(), (codes[len(data) - 1:len(data) - 1 + F] - 63.5) / 64)
+    seq = T.CharSequences(text, F, device="cuda")
+    xs, ys, ids = seq.sample(64, gen)
+    assert xs.dtype == torch.long and xs.shape == (64, F - 1, 1)
+    ic = ids.cpu()
+    want_x = torch.stack([codes[i:i + F - 1] for i in ic.tolist()]).long()
+    want_y = torch.stack([codes[i + 1:i + F] for i in ic.tolist()]).long()
+    assert torch.equal(xs.cpu()[:, :, 0], want_x) and torch.equal(ys.cpu()[:, :, 0], want_y)
