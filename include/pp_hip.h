@@ -83,6 +83,10 @@ enum {
   PP_BWD_W_DENSE = 3,  /* Phi^T x gy on f32 MFMA (small K only) */
   PP_BWD_W_FP16X2 = 5, /* same on fp16 MFMA, operands split 2-way, gy scaled per (512 rows, out) */
   PP_BWD_W_BF16X3 = 4, /* Phi^T x gy on bf16 MFMA, operands split 3-way (small K only) */
+  PP_BWD_W_REGACC = 6, /* many segments (weight rows per input K <= 192, n <= 3): a wave owns one input
+                          x 64 outs, keeps one register per weight row and adds the batch rows in
+                          their natural order through the VGPR index mode; no sort, no zero fill, no
+                          atomics, bitwise reproducible; needs a workspace */
   PP_BWD_X_GATHER = 1,
   PP_BWD_X_DENSE = 2,
   PP_BWD_X_FP16X2 = 4, /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor and gy per

@@ -120,6 +120,8 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
                          : PP_BWD_X_GATHER;
     case 2:
       if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
+      if (pp_regacc_preferred(sh)) return PP_BWD_W_REGACC;
+      if (pp_regacc_supported(sh)) return PP_BWD_W_ATOMIC;  // too small for anything but atomics
       return pp_sort_supported(sh) ? PP_BWD_W_SORT : PP_BWD_W_ATOMIC;
     default: return PP_ERR_METHOD;
   }
@@ -317,6 +319,8 @@ size_t pp_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous, 
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous, length);
   if (method == PP_BWD_W_SORT) return pp_sort_supported(sh) ? pp_sort_workspace_bytes(sh) : 0;
+  if (method == PP_BWD_W_REGACC)
+    return pp_regacc_supported(sh) ? pp_regacc_workspace_bytes(sh) : 0;
   if (method == PP_BWD_W_DENSE)
     return pp_dense_supported(sh) ? pp_dense_bwd_weight_workspace_bytes(sh) : 0;
   if (method == PP_BWD_W_BF16X3 || method == PP_BWD_W_FP16X2)
@@ -346,6 +350,12 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
       const size_t need = pp_sort_workspace_bytes(sh);
       if (!workspace || workspace_bytes < need) return PP_ERR_WORKSPACE;
       return hip_rc(pp_launch_bwd_weight_sort(x, gy, gw_t, workspace, sh, tab, st));
+    }
+    case PP_BWD_W_REGACC: {
+      if (!pp_regacc_supported(sh)) return PP_ERR_METHOD;
+      const size_t need = pp_regacc_workspace_bytes(sh);
+      if (!workspace || workspace_bytes < need) return PP_ERR_WORKSPACE;
+      return hip_rc(pp_launch_bwd_weight_regacc(x, gy, gw_t, workspace, sh, tab, st));
     }
     case PP_BWD_W_DENSE: {
       if (!pp_dense_supported(sh)) return PP_ERR_METHOD;

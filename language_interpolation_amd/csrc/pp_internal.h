@@ -40,6 +40,13 @@ bool pp_sort_supported(const PPShape& sh);
 hipError_t pp_launch_bwd_weight_sort(const float* x, const float* gy, float* gwt, void* ws,
                                      const PPShape& sh, const BasisTab& tab, hipStream_t st);
 
+// ---- register-resident accumulator tables (pp_regacc.hip) ----
+bool pp_regacc_supported(const PPShape& sh);
+bool pp_regacc_preferred(const PPShape& sh);
+size_t pp_regacc_workspace_bytes(const PPShape& sh);
+hipError_t pp_launch_bwd_weight_regacc(const float* x, const float* gy, float* gwt, void* ws,
+                                       const PPShape& sh, const BasisTab& tab, hipStream_t st);
+
 // ---- dense f32-MFMA path (pp_dense.hip) ----
 bool pp_dense_supported(const PPShape& sh);
 size_t pp_dense_bwd_weight_workspace_bytes(const PPShape& sh);

@@ -1,0 +1,242 @@
+// Weight gradient of the many-segment layers with the accumulators in registers.
+//
+//   gw_t[i, k, o] = sum over rows b of  l_j(xi[b,i]) * gy[b, o]   for k = k0(b,i) + j, j < n
+//
+// A wave owns one input i and 64 consecutive outs (lane <-> out) and keeps ONE VGPR PER TABLE ROW k
+// (K <= 192 rows, v64..v255, or v96..v255 for K <= 160).  It walks the batch rows in their natural order: gy[b, 64 outs] is
+// one coalesced load, and the row is added into the registers k0..k0+n-1 picked by the row's
+// segment through the VGPR index mode of gfx9 (s_set_gpr_idx_idx + v_fma_f32, two or three
+// instructions per row).  Nothing is sorted, nothing is zero-filled and no atomics are used: every
+// table row is produced by exactly one wave and stored once (rows no batch row hits store 0).
+// When inputs x out chunks are too few waves to fill the GPU (the 16-input first layers), the
+// batch is cut into slices whose tables go to the workspace and are summed by the partial-sum
+// kernel of pp_dense.hip.
+//
+// The segment/basis evaluation is hoisted into a prepass that writes, per input and per 64 rows,
+// the scalars the loop needs (k0 and, for n >= 2, the n basis values) transposed, so that the
+// main loop fetches them with one coalesced load per 64 rows (lane <-> row) and broadcasts them
+// with v_readlane: pp_regacc_prep_kernel.  The loop itself is generated assembly
+// (tools/gen_regacc_asm.py -> pp_regacc_body.inc; the register map is documented there): the
+// compiler has no way to express a register-indexed accumulate (an indexed array of this size is
+// placed in scratch memory).
+//
+// Replaces autograd's index_put_(accumulate=True) scatter into w.grad (loss.backward() at
+// networks.py:164-165 of the reference), like pp_sort.hip; measured against it in
+// profiles/r02_e_layer_bench.txt.
+#include "pp_device.h"
+#include "pp_regacc_body.inc"
+
+namespace {
+
+constexpr int kRB = 16;   // rows per block of gy loads
+constexpr int kSB = 64;   // rows per set of record registers (lane <-> row)
+constexpr int planes_of(int n) { return n == 1 ? 1 : 1 + n; }
+
+struct RegaccPlan {
+  int nblk;        // blocks of kRB rows covering the batch
+  int nsb;         // super-blocks of kSB rows covering the batch
+  int nchunk;      // out chunks of 64
+  int nquad;       // groups of 4 inputs (one workgroup = 4 waves = 4 inputs, same rows and outs)
+  int sbps;        // super-blocks per slice
+  int nslice;      // row slices (1 = tables go straight to gw)
+  size_t rec_ints_per_input;
+  size_t off_rec, off_part, bytes;
+};
+
+RegaccPlan make_plan(const PPShape& sh) {
+  RegaccPlan p;
+  p.nblk = (sh.B + kRB - 1) / kRB;
+  p.nsb = (sh.B + kSB - 1) / kSB;
+  p.nchunk = (sh.O + 63) / 64;
+  p.nquad = (sh.I + 3) / 4;
+  const long waves_full = (long)sh.I * p.nchunk;
+  long ns = 1;
+  if (waves_full < 768) ns = (1024 + waves_full - 1) / waves_full;
+  ns = std::min<long>(ns, std::max<long>(1, p.nsb / 4));  // at least 256 rows per slice
+  const size_t table = (size_t)sh.I * sh.K * sh.O * sizeof(float);
+  ns = std::min<long>(ns, std::max<long>(1, (long)((96u << 20) / table)));
+  p.sbps = (int)((p.nsb + ns - 1) / ns);
+  p.nslice = (p.nsb + p.sbps - 1) / p.sbps;
+  p.rec_ints_per_input = (size_t)(p.nsb + 1) * planes_of(sh.n) * kSB;  // one super-block of slack
+  size_t o = 0;
+  p.off_rec = o;
+  o += ((size_t)sh.I * p.rec_ints_per_input * sizeof(int) + 255) & ~(size_t)255;
+  p.off_part = o;
+  if (p.nslice > 1) o += (size_t)p.nslice * table;
+  p.bytes = o;
+  return p;
+}
+
+// Prepass: rec[i][sb][0][r] = k0 of row sb*64+r (first table row of its segment) and, for
+// n >= 2, rec[i][sb][1+j][r] = l_j(xi).  Rows past the batch get k0 = 0 and zero basis values.
+// One workgroup = 64 rows x 32 inputs, transposed through LDS (x is read along a row, the
+// records are written along the batch).
+template <int N>
+__global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __restrict__ x,
+                                                             int* __restrict__ rec, PPShape sh,
+                                                             BasisTab tab,
+                                                             size_t rec_ints_per_input) {
+  constexpr int P = planes_of(N);
+  __shared__ int tile[P][32][65];
+  const int t = threadIdx.x;
+  const int b0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
+  {
+    const int col = t & 31, rp = t >> 5;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int rl = rr * 8 + rp;
+      const int b = b0 + rl, i = i0 + col;
+      int k0 = 0;
+      float l[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) l[j] = 0.0f;
+      if (b < sh.B && i < sh.I) {
+        const float xv = x[(size_t)b * sh.I + i];
+        const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
+        if constexpr (N > 1) {
+          const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
+          pp_lagrange<N>(xi, tab, l);
+        }
+        k0 = s * sh.stride;
+      }
+      tile[0][col][rl] = k0;
+      if constexpr (N > 1) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) tile[1 + j][col][rl] = __float_as_int(l[j]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int rl = t & 63, cp = t >> 6;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int col = cc * 4 + cp;
+      const int i = i0 + col;
+      if (i < sh.I) {
+        int* dst = rec + (size_t)i * rec_ints_per_input + (size_t)blockIdx.x * P * kSB + rl;
+#pragma unroll
+        for (int j = 0; j < P; ++j) dst[j * kSB] = tile[j][col][rl];
+      }
+    }
+  }
+}
+
+struct RegaccArgs {
+  int B, I, O, K, nchunk, nquad, sbps, nblk;
+  size_t rec_ints_per_input;
+  size_t slice_stride;  // floats between the tables of two slices
+  float scale;
+};
+
+#define PP_REGACC_ASM(BODY)                                                                       \
+  asm volatile(BODY                                                                               \
+               :                                                                                  \
+               : [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [dst] "s"(d),            \
+                 [rec] "s"(recp), [nblk] "s"(nblk), [rowb] "s"(rowb), [K] "s"(K),                 \
+                 [scale] "s"(scale), [laneb] "v"(laneb), [vok] "v"(vok), [lane4] "v"(lane4)       \
+               : PP_REGACC_CLOBBERS)
+
+// DEEP: the variant for K <= PP_REGACC_KDEEP (64 staging registers: gy loads run 3 blocks ahead).
+template <int N, bool DEEP>
+__global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* __restrict__ gy,
+                                                                   const int* __restrict__ rec,
+                                                                   float* __restrict__ dst,
+                                                                   RegaccArgs a) {
+  constexpr int P = planes_of(N);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  int bid = blockIdx.x;
+  const int q = bid % a.nquad;
+  bid /= a.nquad;
+  const int c = bid % a.nchunk;
+  const int slice = bid / a.nchunk;
+  const int i = q * 4 + wave;
+  if (i >= a.I) return;  // whole wave
+  const int sb0 = slice * a.sbps;
+  const int blk0 = sb0 * (kSB / kRB);
+  const int nblk = min(a.sbps * (kSB / kRB), a.nblk - blk0);  // >= 1 by the plan
+  const long row0 = (long)blk0 * kRB;
+  const unsigned long long gaddr = (unsigned long long)(gy + row0 * a.O);
+  // buffer resource: base, stride 0, num_records = bytes from base to the end of gy, raw dword
+  const int r0 = (int)(unsigned)(gaddr & 0xffffffffull);
+  const int r1 = (int)(unsigned)((gaddr >> 32) & 0xffffull);
+  const int r2 = (int)(unsigned)(((long)a.B - row0) * a.O * 4);
+  const int r3 = 0x00020000;
+  const int* recp = rec + (size_t)i * a.rec_ints_per_input + (size_t)sb0 * P * kSB;
+  float* d = dst + (size_t)slice * a.slice_stride + (size_t)i * a.K * a.O;
+  const int o = c * 64 + lane;
+  const int laneb = o * 4;
+  const int lane4 = lane * 4;
+  const int vok = o < a.O ? 1 : 0;
+  const int rowb = a.O * 4;
+  const int K = a.K;
+  const float scale = a.scale;
+  if constexpr (N == 1 && DEEP) {
+    PP_REGACC_ASM(PP_REGACC_BODY_N1_K160);
+  } else if constexpr (N == 1) {
+    PP_REGACC_ASM(PP_REGACC_BODY_N1_K192);
+  } else if constexpr (N == 2 && DEEP) {
+    PP_REGACC_ASM(PP_REGACC_BODY_N2_K160);
+  } else if constexpr (N == 2) {
+    PP_REGACC_ASM(PP_REGACC_BODY_N2_K192);
+  } else if constexpr (DEEP) {
+    PP_REGACC_ASM(PP_REGACC_BODY_N3_K160);
+  } else {
+    PP_REGACC_ASM(PP_REGACC_BODY_N3_K192);
+  }
+}
+
+template <int N>
+hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const PPShape& sh,
+                  const BasisTab& tab, hipStream_t st) {
+  const RegaccPlan p = make_plan(sh);
+  char* base = static_cast<char*>(ws);
+  int* rec = reinterpret_cast<int*>(base + p.off_rec);
+  float* part = reinterpret_cast<float*>(base + p.off_part);
+  // the slack super-block is written too (zeros)
+  hipLaunchKernelGGL((pp_regacc_prep_kernel<N>), dim3(p.nsb + 1, (sh.I + 31) / 32), dim3(256), 0,
+                     st, x, rec, sh, tab, p.rec_ints_per_input);
+  RegaccArgs a;
+  a.B = sh.B; a.I = sh.I; a.O = sh.O; a.K = sh.K;
+  a.nchunk = p.nchunk; a.nquad = p.nquad; a.sbps = p.sbps; a.nblk = p.nblk;
+  a.rec_ints_per_input = p.rec_ints_per_input;
+  a.slice_stride = (size_t)sh.I * sh.K * sh.O;
+  a.scale = p.nslice > 1 ? 1.0f : sh.out_scale;
+  float* dst = p.nslice > 1 ? part : gwt;
+  const dim3 grid(p.nquad * p.nchunk * p.nslice);
+  if (sh.K <= PP_REGACC_KDEEP)
+    hipLaunchKernelGGL((pp_bwd_weight_regacc_kernel<N, true>), grid, dim3(256), 0, st, gy,
+                       (const int*)rec, dst, a);
+  else
+    hipLaunchKernelGGL((pp_bwd_weight_regacc_kernel<N, false>), grid, dim3(256), 0, st, gy,
+                       (const int*)rec, dst, a);
+  if (p.nslice > 1)
+    pp_launch_chunk_reduce(part, gwt, (long)sh.I * sh.K * sh.O, p.nslice, sh.out_scale, st);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool pp_regacc_supported(const PPShape& sh) {
+  return sh.K <= PP_REGACC_KMAX && sh.n <= 3 && (long)sh.B * sh.O * 4 < (1L << 31) &&
+         (long)sh.O * 4 * 16 < (1L << 24);
+}
+
+// Where it measured fastest (profiles/r02_e_layer_bench.txt): every supported shape, except the
+// very small ones where a few million float atomics are cheaper than its three launches.
+bool pp_regacc_preferred(const PPShape& sh) {
+  return pp_regacc_supported(sh) && (long)sh.B * sh.I * sh.n * sh.O >= 2500000L;
+}
+
+size_t pp_regacc_workspace_bytes(const PPShape& sh) { return make_plan(sh).bytes; }
+
+hipError_t pp_launch_bwd_weight_regacc(const float* x, const float* gy, float* gwt, void* ws,
+                                       const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  switch (sh.n) {
+    case 1: return launch<1>(x, gy, gwt, ws, sh, tab, st);
+    case 2: return launch<2>(x, gy, gwt, ws, sh, tab, st);
+    case 3: return launch<3>(x, gy, gwt, ws, sh, tab, st);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -168,14 +168,16 @@ SlabPlan slab_plan(const PPShape& sh, bool prefer) {
     }
   }
   if (!best.ok || !prefer) return best;
-  // Measured on MI355X at 16384 rows (profiles/r02_b_layer_bench.txt): cfg4 input layer
+  // Measured on MI355X at 16384 rows (profiles/r02_e_layer_bench.txt): cfg4 input layer
   // (K = 256, O = 1000) 80 us vs 92 us for the gather kernel; cfg1/cfg2 input layers
   // (K = 129, O = 200/250) 36/46 us vs 25/37 us.  The gather loop is bound by vector
   // instructions per (row, input, 64 outs) -- 6 here with one float per lane against ~3.3 in
   // the gather kernel's four-floats-per-lane form -- so the slab only pays where the table is
-  // too large for the gather kernel's L2 traffic to stay cheap.
+  // too large for the gather kernel's L2 traffic to stay cheap, and only for few inputs: at 200
+  // inputs (cfg3 with n = 2, K = 300) it lost, 431 vs 394 us, the per-input barrier showing.
   const long blocks = (long)best.ntile * best.nchunk;
-  if (sh.B < 4096 || blocks < 192 || sh.K < 192 || (long)sh.I * sh.K * sh.O * 4 < (8L << 20))
+  if (sh.B < 4096 || blocks < 192 || sh.K < 192 || sh.I > 32 ||
+      (long)sh.I * sh.K * sh.O * 4 < (8L << 20))
     best.ok = false;
   return best;
 }

@@ -53,7 +53,20 @@ def test_auto_method_selection():
     # many segments -> gather / sort
     assert lib.pp_auto_method(0, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.FWD_GATHER
     assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.BWD_W_SORT
-    assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1, 2.0) == _lib.BWD_W_SORT
+    # ... up to 192 weight rows per input and n <= 3: accumulators in registers
+    assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1, 2.0) == _lib.BWD_W_REGACC
+    assert lib.pp_auto_method(2, 16384, 16, 250, 2, 128, 0, 2.0) == _lib.BWD_W_REGACC
+    assert lib.pp_auto_method(2, 64, 16, 250, 2, 128, 0, 2.0) == _lib.BWD_W_ATOMIC  # tiny
+    assert lib.pp_auto_method(2, 4096, 200, 200, 2, 150, 1, 2.0) == _lib.BWD_W_SORT  # K = 300
+    assert lib.pp_auto_method(2, 4096, 64, 64, 4, 40, 1, 2.0) == _lib.BWD_W_SORT     # n = 4
+    assert lib.pp_workspace_bytes(1000, 200, 200, 1, 150, 1, 2.0, _lib.BWD_W_REGACC) > 0
+    assert lib.pp_workspace_bytes(1000, 16, 1000, 2, 128, 1, 2.0, _lib.BWD_W_REGACC) == 0  # K = 256
+    null = ctypes.c_void_p(0)
+    fake = ctypes.c_void_p(0x1000)
+    assert lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 1000, 16, 1000, 2, 128, 1, 2.0,
+                                      null, 1.0, _lib.BWD_W_REGACC, null) == -5  # not this shape
+    assert lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 1000, 200, 200, 1, 150, 1, 2.0,
+                                      null, 1.0, _lib.BWD_W_REGACC, null) == -4  # no workspace
     # few segments, wide layer -> expanded basis on the matrix cores (cfg2 hidden, cfg1 hidden)
     for p, want in ((0, _lib.FWD_FP16X2), (1, _lib.BWD_X_FP16X2), (2, _lib.BWD_W_DENSE)):
         assert lib.pp_auto_method(p, 256, 250, 250, 3, 2, 0, 2.0) == want
@@ -64,7 +77,7 @@ def test_auto_method_selection():
     # networks.py:386-425) keeps the layer off the matrix-core kernels
     assert lib.pp_auto_method(0, 256, 250, 250, 3, 2, 0, 3.0) == _lib.FWD_GATHER
     assert lib.pp_auto_method(1, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_X_GATHER
-    assert lib.pp_auto_method(2, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_W_SORT
+    assert lib.pp_auto_method(2, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_W_REGACC
     assert lib.pp_packed_weights_bytes(250, 250, 3, 2, 0, 3.0) == 0
     assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 3.0) == 0
     assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 1

@@ -8,6 +8,8 @@ Launching every instantiation at that occupancy several times and demanding iden
 the sharpest detector for that class of fault; a row-wise comparison against the plain-fp32
 gather kernels catches a fault that became repeatable.
 """
+import dataclasses
+
 import pytest
 import torch
 
@@ -92,7 +94,7 @@ def test_non_power_of_two_length_takes_the_gather_path_through_the_module():
     from oracle import pp_oracle as po
     lib = _lib.load()
     assert lib.pp_auto_method(0, 512, 64, 64, 3, 2, 0, 3.0) == _lib.FWD_GATHER
-    assert lib.pp_auto_method(2, 512, 64, 64, 3, 2, 0, 3.0) == _lib.BWD_W_SORT
+    assert lib.pp_auto_method(2, 512, 64, 64, 3, 2, 0, 3.0) == _lib.BWD_W_REGACC  # plain fp32
     assert lib.pp_packed_weights_bytes(64, 64, 3, 2, 0, 3.0) == 0
     assert lib.pp_packed_weights_bytes(64, 64, 3, 2, 0, 4.0) > 0
     torch.manual_seed(3)
@@ -161,7 +163,7 @@ def test_slab_forward_matches_oracle_and_gather(case):
     lib = _lib.load()
     # PP_METHOD_AUTO takes the slab only where it measured faster (large tables, large batch)
     K = n * S if disc else (n - 1) * S + 1
-    big = B >= 4096 and K >= 192 and I * K * O * 4 >= (8 << 20)
+    big = B >= 4096 and K >= 192 and I <= 32 and I * K * O * 4 >= (8 << 20)
     want = _lib.FWD_SLAB if big else _lib.FWD_GATHER
     assert lib.pp_auto_method(0, B, I, O, n, S, int(disc), 2.0) == want, "planner"
     PF = _pf()
@@ -181,6 +183,53 @@ def test_slab_forward_matches_oracle_and_gather(case):
     ref = oracle_all(x[rows], w, gy[rows], n, S, disc)
     assert torch.equal(seg[rows].cpu().long(), ref["seg"].long())
     assert rel_err(y[rows].cpu(), ref["y"]) <= TOL
+
+
+# (disc, n, S, I, O, B, dist, out_scale): shapes of the register-accumulator weight gradient --
+# both register layouts (K <= 160 / <= 192), n = 1..3, batches that end inside a block of 16 and
+# inside a set of 64 rows, sliced (few inputs) and unsliced grids, ragged out chunks
+REGACC_CASES = [
+    (True, 1, 150, 200, 200, 4096, "normal", 1.0),      # cfg3 hidden layer
+    (True, 1, 150, 200, 200, 1000, "normal", 1.0),      # ... at the reference's batch
+    (False, 2, 128, 16, 250, 16384, "char", 1.0),       # cfg2 input layer: 16 slices
+    (False, 2, 128, 16, 200, 256, "char", 0.5),         # cfg1 input layer at the reference's batch
+    (True, 2, 64, 16, 1000, 4096 + 3, "char", 1.0),     # 16 out chunks, ragged rows
+    (False, 3, 50, 37, 70, 777, "edges", 1.0),          # n = 3, boundary values, 37 inputs
+    (True, 3, 64, 5, 64, 129, "normal", 2.0),           # K = 192: the shallow register layout
+    (True, 1, 192, 3, 1, 17, "uniform", 1.0),           # one out, less than one block of rows
+    (False, 2, 191, 9, 130, 2049, "normal", 1.0),       # K = 192 continuous
+]
+
+
+@pytest.mark.parametrize("case", REGACC_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
+    from language_interpolation_amd import _lib
+    disc, n, S, I, O, B, dist, scale = case
+    lib = _lib.load()
+    K = n * S if disc else (n - 1) * S + 1
+    want = _lib.BWD_W_REGACC if B * I * n * O >= 2500000 else _lib.BWD_W_ATOMIC
+    assert lib.pp_auto_method(2, B, I, O, n, S, int(disc), 2.0) == want, "planner"
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=90 + n)
+    xd, gyd = x.cuda(), gy.cuda()
+    spec = PF.make_spec(n, S, disc, bwd_w_method="regacc", in_features=I)
+    spec = dataclasses.replace(spec, out_scale=scale)
+    gw = PF.backward_weight_raw(xd, gyd, (I, K, O), spec)
+    # fixed order of the rows inside every accumulator: the same bits every time
+    for _ in range(2):
+        assert torch.equal(PF.backward_weight_raw(xd, gyd, (I, K, O), spec), gw)
+    sort_spec = PF.make_spec(n, S, disc, bwd_w_method="sort", in_features=I)
+    gs = PF.backward_weight_raw(xd, gyd, (I, K, O), sort_spec) * scale
+    assert rel_err(gw.cpu(), gs.cpu()) <= TOL
+    rows = slice(max(0, B - 1200), B)   # the oracle on the LAST rows: the ragged end of the batch
+    head = slice(0, max(0, B - 1200))
+    ref = oracle_all(x[rows], w, gy[rows], n, S, disc)
+    gw_tail = gw
+    if head.stop > 0:
+        gw_tail = gw - PF.backward_weight_raw(xd[head].contiguous(), gyd[head].contiguous(),
+                                              (I, K, O), spec)
+    want_gw = ref["gw"].permute(1, 2, 0) * scale   # [O, I, K] -> kernel layout [I, K, O]
+    assert rel_err(gw_tail.cpu(), want_gw) <= 4 * TOL
 
 
 # BASELINE layer shapes at the bench batch (dense-regime layers) / a quarter of it (many-segment

@@ -144,7 +144,8 @@ def test_char_windows_and_sequences_are_exact_on_the_device():
     gen = torch.Generator(device="cuda").manual_seed(5)
     x, y, ids = data.sample(512, gen)
     assert x.is_cuda and y.is_cuda and x.shape == (512, F) and y.shape == (512, 1)
-    codes = torch.tensor([ord(c) for c in text], dtype=torch.float32)
+    raw = text if isinstance(text, (bytes, bytearray)) else text.encode("ascii", "ignore")
+    codes = torch.tensor(list(raw), dtype=torch.float32)
     idc = ids.cpu()
     win = torch.stack([codes[i:i + F] for i in idc.tolist()])
     assert torch.equal(x.cpu(), (win - 64 + 0.5) / 64)
