@@ -193,13 +193,17 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
 int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream);
 int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* stream);
 
-/* Forward of a dense-regime layer with the FOLLOWING non-affine LayerNorm fused into the
- * kernel's epilogue (the layer -> LazyLayerNormLastDim pairs of HighOrderMLP,
- * networks.py:866-882 with normalization=LazyLayerNormLastDim): y = LN(layer(x)), rstd[B] as
- * pp_layer_norm_fwd_f32 writes it (pp_layer_norm_bwd_f32 is the matching backward).  Runs the
- * fp16x2 kernel on weights pre-split by pp_pack_weights_f32 (`packed`).
- * pp_forward_layer_norm_supported: 1 when this shape has the fused kernel (dense regime,
- * O <= 256) and it is what PP_METHOD_AUTO would run. */
+/* Forward of a layer with the FOLLOWING non-affine LayerNorm fused into the kernel's epilogue
+ * (the layer -> LazyLayerNormLastDim pairs of HighOrderMLP, networks.py:866-882 with
+ * normalization=LazyLayerNormLastDim): y = LN(layer(x)), rstd[B] as pp_layer_norm_fwd_f32
+ * writes it (pp_layer_norm_bwd_f32 is the matching backward).  Two kernels:
+ *   packed != NULL: the fp16x2 matrix-core kernel on weights pre-split by pp_pack_weights_f32
+ *                   (dense regime, O <= 256);
+ *   packed == NULL: the gather kernel with whole rows per wave (many-segment layers, first
+ *                   layers, lengths off the matrix-core path; n <= 4, O <= 1024, O >= 4),
+ *                   bit-identical to pp_forward_f32(PP_FWD_GATHER) + pp_layer_norm_fwd_f32.
+ * pp_forward_layer_norm_supported: 1 / 2 when the first / second is what a caller should run
+ * for this shape (the kernel PP_METHOD_AUTO would pick for the layer alone has it), else 0. */
 int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
                                     float length);
 int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float* rstd,

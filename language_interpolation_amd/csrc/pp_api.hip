@@ -399,11 +399,17 @@ int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float*
                               void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
                               int discontinuous, float length, const float* nodes, float out_scale,
                               float eps, void* stream) {
-  if (!x || !w_t || !y || !rstd || !packed) return PP_ERR_NULL;
+  if (!x || !w_t || !y || !rstd) return PP_ERR_NULL;
   if (!aligned16(x) || !aligned16(w_t) || !aligned16(y) || !aligned16(packed)) return PP_ERR_ALIGN;
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
   if (rc != PP_OK) return rc;
+  if (!packed) {  // gather path: the wave that sums a row normalises it
+    if (!pp_gather_ln_supported(sh)) return PP_ERR_METHOD;
+    BasisTab gtab;
+    make_basis(gtab, n, length, nodes);
+    return hip_rc(pp_launch_fwd_gather_ln(x, w_t, y, rstd, sh, gtab, eps, (hipStream_t)stream));
+  }
   if (!pp_h2_fwd_ln_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
   if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
   BasisTab tab;
@@ -416,8 +422,13 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
                                     float length) {
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
-  return pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && dense_preferred(sh) &&
-         sh.B >= 256;
+  if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && dense_preferred(sh) &&
+      sh.B >= 256)
+    return 1;
+  // layers the gather kernels serve (many segments, first layers, lengths off the matrix-core
+  // path): fused there too
+  if (!dense_preferred(sh) && pp_gather_ln_supported(sh)) return 2;
+  return 0;
 }
 
 static int scan_args_ok(int b, int l, int d, int n) {

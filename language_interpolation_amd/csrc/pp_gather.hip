@@ -99,6 +99,111 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------
+// forward with the non-affine LayerNorm over the row fused into the epilogue
+// (LazyLayerNormLastDim, /root/reference/language_interpolation/networks.py:72-91): a wave owns
+// whole rows (CH chunks of 64*V outs per lane, O <= 1024), so the row it has just summed is
+// normalised in registers and the raw layer output never exists in memory.  Same order of the
+// sum over inputs as pp_fwd_gather_kernel and the same reductions as pp_layer_norm_fwd_kernel
+// (pp_norm.hip) at the same V: bit-identical to running the two kernels one after the other.
+// ---------------------------------------------------------------------------
+template <int N, int V, int CH>
+__global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ wt,
+                                                               float* __restrict__ y,
+                                                               float* __restrict__ rstd,
+                                                               PPShape sh, BasisTab tab, float eps) {
+  constexpr int RW = (CH * V <= 8) ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  if (row0 >= sh.B) return;  // wave-uniform; no block barrier below
+  int dcl[CH];
+  bool ok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int d = (c * 64 + lane) * V;
+    ok[c] = d < sh.O;
+    dcl[c] = ok[c] ? d : sh.O - V;  // clamp: every lane loads valid memory
+  }
+  float acc[RW][CH][V];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[r][c][v] = 0.0f;
+
+  for (int i0 = 0; i0 < sh.I; i0 += 64) {
+    const int i = i0 + lane;
+    int koff[RW];
+    float l[RW][N];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int b = min(row0 + r, sh.B - 1);
+      const bool valid = i < sh.I;
+      const float xv = valid ? x[(size_t)b * sh.I + i] : 0.0f;
+      const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
+      const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
+      pp_lagrange<N>(xi, tab, l[r]);
+      koff[r] = (valid ? i : 0) * sh.K + s * sh.stride;
+    }
+    const int cnt = min(64, sh.I - i0);
+    for (int ii = 0; ii < cnt; ++ii) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int ko = pp_readlane_i(koff[r], ii);
+        const float* p = wt + (size_t)ko * sh.O;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const float lj = pp_readlane_f(l[r][j], ii);
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            PPVec<V> wv;
+            wv.load(p + (size_t)j * sh.O + dcl[c]);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[r][c][v] = fmaf(lj, wv.v[v], acc[r][c][v]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    if (row0 + r >= sh.B) break;  // wave-uniform
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        acc[r][c][v] = ok[c] ? acc[r][c][v] * sh.out_scale : 0.0f;
+        s += acc[r][c][v];
+      }
+    const float mean = pp_wave_sum(s) / (float)sh.O;
+    float q = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float d = ok[c] ? acc[r][c][v] - mean : 0.0f;
+        acc[r][c][v] = d;
+        q = fmaf(d, d, q);
+      }
+    const float var = pp_wave_sum(q) / (float)sh.O;
+    const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (ok[c]) {
+        PPVec<V> out;
+#pragma unroll
+        for (int v = 0; v < V; ++v) out.v[v] = acc[r][c][v] * rs;
+        out.store(y + (size_t)(row0 + r) * sh.O + dcl[c]);
+      }
+    }
+    if (lane == 0) rstd[row0 + r] = rs;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // backward w.r.t. the input: one wave per row; lanes span `out`, one wave
 // reduction per (row, input, out-chunk).
 // ---------------------------------------------------------------------------
@@ -344,6 +449,54 @@ hipError_t pp_launch_fwd_gather(const float* x, const float* wt, float* y, int32
 #define CALL(N) fwd_dispatch_v<N>(x, wt, y, seg, sh, tab, st)
   PP_SWITCH_N(sh.n, CALL)
 #undef CALL
+}
+
+// (V, CH) as the row-norm kernels choose them (pp_norm.hip): V by the divisibility of O
+static bool gather_ln_combo(int O, int& V, int& CH) {
+  V = (O % 4 == 0) ? 4 : (O % 2 == 0 ? 2 : 1);
+  const int need = (O + 64 * V - 1) / (64 * V);
+  if (V == 4) CH = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 4 ? 4 : 0));
+  else if (V == 2) CH = need <= 2 ? 2 : (need <= 4 ? 4 : (need <= 8 ? 8 : 0));
+  else CH = need <= 4 ? 4 : 0;
+  return CH != 0;
+}
+
+bool pp_gather_ln_supported(const PPShape& sh) {
+  int V, CH;
+  return sh.n <= 4 && sh.O >= 4 && gather_ln_combo(sh.O, V, CH);
+}
+
+namespace {
+template <int N>
+hipError_t fwd_ln_dispatch(const float* x, const float* wt, float* y, float* rstd,
+                           const PPShape& sh, const BasisTab& tab, float eps, hipStream_t st) {
+  int V, CH;
+  if (!gather_ln_combo(sh.O, V, CH)) return hipErrorInvalidValue;
+#define PP_LN_CASE(V_, CH_)                                                                  \
+  if (V == V_ && CH == CH_) {                                                                \
+    constexpr int RW = (CH_ * V_ <= 8) ? 2 : 1;                                              \
+    hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_>), dim3((sh.B + 4 * RW - 1) / (4 * RW)), \
+                       dim3(256), 0, st, x, wt, y, rstd, sh, tab, eps);                      \
+    return hipGetLastError();                                                                \
+  }
+  PP_LN_CASE(4, 1) PP_LN_CASE(4, 2) PP_LN_CASE(4, 4)
+  PP_LN_CASE(2, 2) PP_LN_CASE(2, 4) PP_LN_CASE(2, 8)
+  PP_LN_CASE(1, 4)
+#undef PP_LN_CASE
+  return hipErrorInvalidValue;
+}
+}  // namespace
+
+hipError_t pp_launch_fwd_gather_ln(const float* x, const float* wt, float* y, float* rstd,
+                                   const PPShape& sh, const BasisTab& tab, float eps,
+                                   hipStream_t st) {
+  switch (sh.n) {
+    case 1: return fwd_ln_dispatch<1>(x, wt, y, rstd, sh, tab, eps, st);
+    case 2: return fwd_ln_dispatch<2>(x, wt, y, rstd, sh, tab, eps, st);
+    case 3: return fwd_ln_dispatch<3>(x, wt, y, rstd, sh, tab, eps, st);
+    case 4: return fwd_ln_dispatch<4>(x, wt, y, rstd, sh, tab, eps, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t pp_launch_bwd_input_gather(const float* x, const float* gy, const float* wt, float* gx,

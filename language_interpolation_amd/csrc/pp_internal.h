@@ -22,6 +22,10 @@ struct BasisTab {
 hipError_t pp_launch_segment_ids(const float* x, int32_t* seg, const PPShape& sh, hipStream_t st);
 hipError_t pp_launch_fwd_gather(const float* x, const float* wt, float* y, int32_t* seg,
                                 const PPShape& sh, const BasisTab& tab, hipStream_t st);
+bool pp_gather_ln_supported(const PPShape& sh);  // fused LayerNorm epilogue: n <= 4, O <= 1024
+hipError_t pp_launch_fwd_gather_ln(const float* x, const float* wt, float* y, float* rstd,
+                                   const PPShape& sh, const BasisTab& tab, float eps,
+                                   hipStream_t st);
 hipError_t pp_launch_bwd_input_gather(const float* x, const float* gy, const float* wt, float* gx,
                                       const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* gwt,

@@ -258,7 +258,8 @@ def layer_norm_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> boo
 
 class PiecewisePolyLayerNormFunction(torch.autograd.Function):
     """y = LayerNorm_lastdim(piecewise_poly(x, w)), the normalisation fused into the forward
-    kernel's epilogue (the block that produces a row normalises it before storing); backward =
+    kernel's epilogue (the block -- matrix-core kernel -- or wave -- gather kernel -- that
+    produces a row normalises it before storing); backward =
     the LayerNorm backward kernel, then the layer's two backward kernels.  Saves (x, w, y, rstd):
     the un-normalised layer output never exists in memory."""
 
@@ -271,14 +272,18 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         B, I = x.shape
         O = w_t.shape[2]
-        packed = pack_weights(w_t, spec, B)
-        if packed is None:
+        mode = lib.pp_forward_layer_norm_supported(B, I, O, spec.n, spec.segments,
+                                                   int(spec.discontinuous), spec.length)
+        packed = pack_weights(w_t, spec, B) if mode == 1 else None
+        if mode == 0 or (mode == 1 and packed is None):
             raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)
         rstd = torch.empty(B, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
+            # mode 2: no packed weights -> the gather kernel with whole rows per wave
             rc = lib.pp_forward_layer_norm_f32(
-                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(packed), packed.numel(), B, I, O,
+                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(packed),
+                packed.numel() if packed is not None else 0, B, I, O,
                 spec.n, spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
                 spec.out_scale, eps, _stream(x.device))
         _lib.check(rc, "pp_forward_layer_norm_f32")

@@ -79,7 +79,11 @@ def test_auto_method_selection():
     assert lib.pp_auto_method(1, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_X_GATHER
     assert lib.pp_auto_method(2, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_W_REGACC
     assert lib.pp_packed_weights_bytes(250, 250, 3, 2, 0, 3.0) == 0
-    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 3.0) == 0
+    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 3.0) == 2  # gather-fused
+    assert lib.pp_forward_layer_norm_supported(1000, 200, 200, 1, 150, 1, 2.0) == 2
+    assert lib.pp_forward_layer_norm_supported(256, 16, 1000, 2, 128, 1, 2.0) == 2
+    assert lib.pp_forward_layer_norm_supported(256, 16, 1030, 2, 128, 1, 2.0) == 0  # O > 1024
+    assert lib.pp_forward_layer_norm_supported(256, 16, 250, 5, 30, 1, 2.0) == 0    # n > 4
     assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 1
     # fp16x2 layers with K >= 7 keep the fused LayerNorm up to 256 outs
     assert lib.pp_forward_layer_norm_supported(256, 64, 256, 4, 2, 0, 2.0) == 1

@@ -112,9 +112,9 @@ def test_non_power_of_two_length_takes_the_gather_path_through_the_module():
         assert rel_err(y.detach(), ref["y"]) <= TOL, length
         assert rel_err(xg.grad, ref["gx"]) <= TOL, length
         assert rel_err(layer.w.grad, ref["gw"]) <= TOL, length
-        # the LayerNorm-fused entry is offered only where the matrix-core kernel runs
-        from language_interpolation_amd import functional as PF
-        assert PF.layer_norm_fusable(xg.detach(), layer.w, layer._spec) == (length == 4.0)
+        # the LayerNorm-fused entry: the matrix-core kernel where it runs, else the gather one
+        assert lib.pp_forward_layer_norm_supported(B, I, O, n, S, 0, length) == \
+            (1 if length == 4.0 else 2)
 
 
 def test_fp16x2_extreme_gradient_scales_stay_finite():
@@ -230,6 +230,52 @@ def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
                                               (I, K, O), spec)
     want_gw = ref["gw"].permute(1, 2, 0) * scale   # [O, I, K] -> kernel layout [I, K, O]
     assert rel_err(gw_tail.cpu(), want_gw) <= 4 * TOL
+
+
+# (disc, n, S, I, O, B, dist): LayerNorm fused into the gather forward -- every (vector width,
+# chunks-per-lane) instantiation, one and two rows per wave, ragged last wave
+GATHER_LN_CASES = [
+    (True, 1, 150, 200, 200, 1000, "normal"),     # cfg3 hidden: V = 4, one chunk
+    (False, 2, 128, 16, 250, 4099, "char"),       # cfg2 input: V = 2, two chunks
+    (True, 2, 128, 16, 1000, 515, "char"),        # cfg4 input: V = 4, four chunks, one row per wave
+    (False, 3, 20, 33, 131, 300, "edges"),        # odd O: V = 1, four chunks
+    (True, 4, 10, 7, 512, 130, "normal"),         # n = 4, V = 4, two chunks
+    (False, 2, 40, 9, 1022, 77, "uniform"),       # V = 2, eight chunks
+    (False, 3, 2, 64, 64, 512, "normal"),         # dense-regime shape sent here by length = 3
+]
+
+
+@pytest.mark.parametrize("case", GATHER_LN_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_gather_forward_with_fused_layer_norm(case):
+    """f2: y = LN(layer(x)) from one kernel == gather forward then the row-norm kernel, bit for
+    bit, and through autograd the same gradients as the unfused module path."""
+    from language_interpolation_amd import _lib
+    disc, n, S, I, O, B, dist = case
+    length = 3.0 if (S == 2) else 2.0
+    lib = _lib.load()
+    assert lib.pp_forward_layer_norm_supported(B, I, O, n, S, int(disc), length) == 2
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=120 + n)
+    xd, wd, gyd = x.cuda(), w.cuda(), gy.cuda()
+    spec = PF.make_spec(n, S, disc, length=length, in_features=I)
+    plain = PF.make_spec(n, S, disc, length=length, fwd_method="gather", in_features=I)
+    w1 = wd.clone().requires_grad_(True)
+    x1 = xd.clone().requires_grad_(True)
+    y1 = PF.piecewise_poly_layer_norm(x1, w1, spec, 1e-5)
+    w2 = wd.clone().requires_grad_(True)
+    x2 = xd.clone().requires_grad_(True)
+    y2 = PF.LayerNormLastFunction.apply(PF.piecewise_poly(x2, w2, plain), 1e-5)
+    assert torch.equal(y1, y2)
+    y1.backward(gyd)
+    y2.backward(gyd)
+    assert rel_err(w1.grad.cpu(), w2.grad.cpu()) <= TOL
+    if n > 1:
+        assert rel_err(x1.grad.cpu(), x2.grad.cpu()) <= TOL
+    # ... and the fp64 oracle of the pair on a slice of the rows
+    rows = slice(0, min(B, 400))
+    ref = oracle_all(x[rows], w, gy[rows], n, S, disc, length=length)
+    yr = torch.nn.functional.layer_norm(ref["y"].double(), (O,), None, None, 1e-5)
+    assert (y1[rows].cpu().double() - yr).abs().max().item() <= 2e-5 * yr.abs().max().item()
 
 
 # BASELINE layer shapes at the bench batch (dense-regime layers) / a quarter of it (many-segment
