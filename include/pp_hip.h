@@ -153,6 +153,16 @@ size_t pp_packed_weights_bytes(int I, int O, int n, int S, int discontinuous, fl
 int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int I, int O, int n,
                         int S, int discontinuous, float length, void* stream);
 
+/* The same for up to PP_PACK_MAX_LAYERS layers in two launches (one absmax, one pack, the
+ * layers' blocks side by side): what a training step calls once for all its dense-regime layers
+ * instead of pp_pack_weights_f32 per layer (2 x count launches of a few microseconds each).
+ * Arrays of `count` entries, meaning as in pp_pack_weights_f32.  No reference counterpart. */
+#define PP_PACK_MAX_LAYERS 16
+int pp_pack_weights_multi_f32(int count, const float* const* w_t, void* const* packed,
+                              const size_t* packed_bytes, const int* I, const int* O, const int* n,
+                              const int* S, const int* discontinuous, const float* length,
+                              void* stream);
+
 /* Backward w.r.t. the input (A4' of SURVEY.md 8(a)):
  * gx[b,i] = out_scale * (L/(x_max-x_min)) * sum_o gy[b,o] * sum_j l'_j(xi) * w_t[i, s*stride+j, o].
  * Replaces autograd's backward through gather/einsum (loss.backward(), networks.py:164-165).

@@ -162,6 +162,26 @@ int pp_pack_weights_f32(const float* w_t, void* packed, size_t packed_bytes, int
   return hip_rc(hipGetLastError());
 }
 
+int pp_pack_weights_multi_f32(int count, const float* const* w_t, void* const* packed,
+                              const size_t* packed_bytes, const int* I, const int* O, const int* n,
+                              const int* S, const int* discontinuous, const float* length,
+                              void* stream) {
+  if (count < 1 || count > PP_PACK_MAX_LAYERS) return PP_ERR_SHAPE;
+  if (!w_t || !packed || !packed_bytes || !I || !O || !n || !S || !discontinuous || !length)
+    return PP_ERR_NULL;
+  PPShape shapes[PP_PACK_MAX_LAYERS];
+  for (int l = 0; l < count; ++l) {
+    if (!w_t[l] || !packed[l]) return PP_ERR_NULL;
+    if (!aligned16(w_t[l]) || !aligned16(packed[l])) return PP_ERR_ALIGN;
+    int rc = make_shape(shapes[l], 256, I[l], O[l], n[l], S[l], discontinuous[l], length[l], 1.0f);
+    if (rc != PP_OK) return rc;
+    if (!pp_bf3_supported(shapes[l]) || !pp_bf3_bwd_x_supported(shapes[l])) return PP_ERR_METHOD;
+    if (packed_bytes[l] < packed_weights_bytes(shapes[l])) return PP_ERR_WORKSPACE;
+  }
+  pp_launch_pack_multi_h2(count, w_t, packed, shapes, (hipStream_t)stream);
+  return hip_rc(hipGetLastError());
+}
+
 static int fwd_auto(const PPShape& sh, bool have_ws) {
   if (!dense_preferred(sh)) return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
   if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_FP16X2;

@@ -187,8 +187,8 @@ __device__ __forceinline__ u32x4 pack8(const unsigned* pc) {
 // (always launched with kAbsmaxBlocks blocks: no zero-fill, no atomics; consumers take the
 // max of the 64 partials with scalar loads)
 constexpr int kAbsmaxBlocks = 64;
-__global__ __launch_bounds__(256) void pp_absmax_kernel(const float* __restrict__ v, long n,
-                                                        unsigned* __restrict__ part) {
+__device__ __forceinline__ void absmax_body(const float* __restrict__ v, long n,
+                                            unsigned* __restrict__ part) {
   __shared__ unsigned wm[4];
   unsigned m = 0;
   const long n4 = n >> 2;
@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256) void pp_absmax_kernel(const float* __restrict_
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+__global__ __launch_bounds__(256) void pp_absmax_kernel(const float* __restrict__ v, long n,
+                                                        unsigned* __restrict__ part) {
+  absmax_body(v, n, part);
 }
 
 __device__ __forceinline__ unsigned absmax_of_parts(const void* hdr) {

@@ -515,6 +515,58 @@ __global__ __launch_bounds__(256) void pp_h2_pack_both_kernel(const float* __res
 }
 }  // namespace
 
+// ---- the same for several layers at once (pp_pack_weights_multi_f32): a training step packs
+// every dense-regime layer's weights once; eight launches of 4-8 us each, all latency, become
+// two whose blocks run side by side.
+struct PackDesc {
+  const float* wt;
+  void* ws;
+  long n;
+  unsigned q_off;
+  int nblk_p, nblk_q, I, K, O, nstep, nso, Ipad;
+};
+struct PackDescs {
+  PackDesc d[PP_PACK_MAX_LAYERS];
+};
+namespace {
+__global__ __launch_bounds__(256) void pp_absmax_multi_kernel(PackDescs ds) {
+  const PackDesc& d = ds.d[blockIdx.y];
+  absmax_body(d.wt, d.n, static_cast<unsigned*>(d.ws));
+}
+__global__ __launch_bounds__(256) void pp_h2_pack_multi_kernel(PackDescs ds) {
+  const PackDesc& d = ds.d[blockIdx.y];
+  const int b = blockIdx.x;
+  if (b < d.nblk_p)
+    pack_w_body<SchemeH2>((long)b * 256 + threadIdx.x, d.wt, d.ws, d.I, d.K, d.O, d.nstep);
+  else if (b < d.nblk_p + d.nblk_q)
+    pack_wo_body<SchemeH2>((long)(b - d.nblk_p) * 256 + threadIdx.x, d.wt, d.ws, d.q_off, d.I, d.K,
+                           d.O, d.nso, d.Ipad);
+}
+}  // namespace
+
+void pp_launch_pack_multi_h2(int count, const float* const* wt, void* const* ws,
+                             const PPShape* shapes, hipStream_t st) {
+  PackDescs ds;
+  int maxblk = 0;
+  for (int l = 0; l < count; ++l) {
+    const PPShape& sh = shapes[l];
+    PackDesc& d = ds.d[l];
+    d.wt = wt[l];
+    d.ws = ws[l];
+    d.n = (long)sh.I * sh.K * sh.O;
+    d.q_off = (unsigned)pp_h2_fwd_packed_bytes(sh);
+    d.I = sh.I; d.K = sh.K; d.O = sh.O;
+    d.nstep = nstep_of(sh);
+    d.nso = ((sh.O + 31) / 32) * 2;
+    d.Ipad = ((sh.I + 31) / 32) * 32;
+    d.nblk_p = (int)(((long)sh.K * d.nstep * sh.O + 255) / 256);
+    d.nblk_q = (int)(((long)d.nso * sh.K * d.Ipad + 255) / 256);
+    maxblk = std::max(maxblk, d.nblk_p + d.nblk_q);
+  }
+  hipLaunchKernelGGL(pp_absmax_multi_kernel, dim3(kAbsmaxBlocks, count), dim3(256), 0, st, ds);
+  hipLaunchKernelGGL(pp_h2_pack_multi_kernel, dim3(maxblk, count), dim3(256), 0, st, ds);
+}
+
 // header (absmax) | P | Q: what pp_pack_weights_f32 writes
 void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st) {
   const int nstep = nstep_of(sh);

@@ -92,6 +92,8 @@ hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* 
 bool pp_h2_fwd_ln_supported(const PPShape& sh);
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh);
 void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st);
+void pp_launch_pack_multi_h2(int count, const float* const* wt, void* const* ws,
+                             const PPShape* shapes, hipStream_t st);
 size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh);
 bool pp_bf3_bwd_x_supported(const PPShape& sh);
 size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh);

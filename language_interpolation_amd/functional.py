@@ -90,21 +90,75 @@ def kernel_layout(w: torch.Tensor) -> torch.Tensor:
     return wt if wt.is_contiguous() else wt.contiguous()
 
 
-def pack_weights(w_t, spec: LayerSpec, B: int):
-    """Pre-split weights for the fp16x2 kernels (one pass serving this step's forward and
-    backward-input), or None when the layer / method choice does not use them."""
+def _packed_bytes(w_t, spec: LayerSpec, B: int) -> int:
+    """Size of the pre-split weight buffer, 0 when the layer / method choice does not use one."""
     if spec.fwd_method != "auto" or spec.bwd_x_method != "auto" or B == 0:
-        return None
+        return 0
     lib = _lib.load()
     I, K, O = w_t.shape
     args = (B, I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length)
     if lib.pp_auto_method(0, *args) != _lib.FWD_FP16X2 or \
             lib.pp_auto_method(1, *args) != _lib.BWD_X_FP16X2:
-        return None
-    nbytes = lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous),
-                                         spec.length)
+        return 0
+    return lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous),
+                                       spec.length)
+
+
+# buffers written by prepack_layers for the step in flight: (storage pointer, version) -> bytes
+_prepacked = {}
+
+
+def prepack_layers(layers, B: int) -> int:
+    """Pre-split the weights of every layer in `layers` (objects with .w and ._spec) that runs on
+    the fp16x2 kernels at batch B, all in two launches (pp_pack_weights_multi_f32); the layers'
+    forwards of this step then find their buffer instead of packing one by one.  Returns the
+    number of layers packed.  The buffers are keyed by the parameter's storage and version
+    counter, so an optimizer step in between makes them unusable rather than stale."""
+    _prepacked.clear()
+    todo = []
+    for layer in layers:
+        w = layer.w
+        if not w.is_cuda:
+            continue
+        w_t = kernel_layout(w.detach())
+        nbytes = _packed_bytes(w_t, layer._spec, B)
+        if nbytes:
+            todo.append((w, w_t, layer._spec, nbytes))
+    for lo in range(0, len(todo), _lib.PACK_MAX_LAYERS):
+        part = todo[lo:lo + _lib.PACK_MAX_LAYERS]
+        cnt = len(part)
+        bufs = [torch.empty(nb, device=w_t.device, dtype=torch.uint8) for _, w_t, _, nb in part]
+        rc = _lib.load().pp_pack_weights_multi_f32(
+            cnt,
+            (ctypes.c_void_p * cnt)(*[w_t.data_ptr() for _, w_t, _, _ in part]),
+            (ctypes.c_void_p * cnt)(*[b.data_ptr() for b in bufs]),
+            (ctypes.c_size_t * cnt)(*[nb for *_, nb in part]),
+            (ctypes.c_int * cnt)(*[w_t.shape[0] for _, w_t, _, _ in part]),
+            (ctypes.c_int * cnt)(*[w_t.shape[2] for _, w_t, _, _ in part]),
+            (ctypes.c_int * cnt)(*[sp.n for _, _, sp, _ in part]),
+            (ctypes.c_int * cnt)(*[sp.segments for _, _, sp, _ in part]),
+            (ctypes.c_int * cnt)(*[int(sp.discontinuous) for _, _, sp, _ in part]),
+            (ctypes.c_float * cnt)(*[sp.length for _, _, sp, _ in part]),
+            _stream(part[0][1].device))
+        _lib.check(rc, "pp_pack_weights_multi_f32")
+        for (w, w_t, _, _), buf in zip(part, bufs):
+            _prepacked[(w_t.data_ptr(), w._version)] = buf
+    return len(todo)
+
+
+def pack_weights(w_t, spec: LayerSpec, B: int, version=None):
+    """Pre-split weights for the fp16x2 kernels (one pass serving this step's forward and
+    backward-input), or None when the layer / method choice does not use them.  `version`: the
+    parameter's version counter, to pick up a buffer prepack_layers wrote for it."""
+    nbytes = _packed_bytes(w_t, spec, B)
     if not nbytes:
         return None
+    if version is not None:
+        buf = _prepacked.get((w_t.data_ptr(), version))
+        if buf is not None and buf.numel() == nbytes and buf.device == w_t.device:
+            return buf
+    lib = _lib.load()
+    I, K, O = w_t.shape
     packed = torch.empty(nbytes, device=w_t.device, dtype=torch.uint8)
     with torch.cuda.device(w_t.device):
         rc = lib.pp_pack_weights_f32(_ptr(w_t), _ptr(packed), nbytes, I, O, spec.n, spec.segments,
@@ -215,7 +269,7 @@ class PiecewisePolyFunction(torch.autograd.Function):
         _require_gpu(w, "w")
         x = x.contiguous()
         w_t = kernel_layout(w.detach())
-        packed = pack_weights(w_t, spec, x.shape[0])
+        packed = pack_weights(w_t, spec, x.shape[0], version=w._version)
         y, _ = forward_raw(x, w_t, spec, packed=packed)
         ctx.spec = spec
         # the pre-split weights serve this step's backward-input too (w cannot change in
@@ -274,7 +328,7 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         O = w_t.shape[2]
         mode = lib.pp_forward_layer_norm_supported(B, I, O, spec.n, spec.segments,
                                                    int(spec.discontinuous), spec.length)
-        packed = pack_weights(w_t, spec, B) if mode == 1 else None
+        packed = pack_weights(w_t, spec, B, version=w._version) if mode == 1 else None
         if mode == 0 or (mode == 1 and packed is None):
             raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)

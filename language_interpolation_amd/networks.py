@@ -14,6 +14,7 @@ from typing import Callable, Optional
 import torch.nn as nn
 from torch import Tensor
 
+from . import functional as PF
 from .layers import LazyLayerNormLastDim, high_order_fc_layers
 
 
@@ -75,6 +76,9 @@ class HighOrderMLP(nn.Module):
         # same result as self.model(x); a polynomial layer directly followed by
         # LazyLayerNormLastDim runs as one kernel where the layer has the fused epilogue
         mods = list(self.model)
+        if x.is_cuda and x.dim() == 2:
+            # the weights of all matrix-core layers are pre-split for this step in two launches
+            PF.prepack_layers([m for m in mods if hasattr(m, "forward_layer_norm")], x.shape[0])
         i = 0
         while i < len(mods):
             m = mods[i]

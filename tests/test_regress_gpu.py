@@ -318,3 +318,42 @@ def test_rowwise_error_of_auto_methods_on_baseline_shapes(shape):
           f" | row-wise {', '.join(f'{k} {v:.2e}' for k, v in errs.items())}")
     for k, v in errs.items():
         assert v <= ROW_BAR[k], (name, k, v)
+
+
+def test_multi_layer_weight_pack_equals_per_layer_pack():
+    """pp_pack_weights_multi_f32 (two launches for all layers of a step) writes the same bytes as
+    pp_pack_weights_f32 per layer, and the MLP's forward picks the buffers up."""
+    import language_interpolation_amd as L
+    from language_interpolation_amd import networks as NW
+    PF = _pf()
+    torch.manual_seed(11)
+    shapes = [(3, 2, False, 250, 250), (3, 2, False, 250, 128), (2, 2, False, 200, 200),
+              (4, 1, True, 64, 96)]
+    layers = []
+    for n, S, disc, I, O in shapes:
+        layers.append(L.high_order_fc_layers("discontinuous" if disc else "continuous", n=n,
+                                             in_features=I, out_features=O, segments=S,
+                                             device="cuda"))
+    B = 1024
+    assert PF.prepack_layers(layers, B) == len(layers)
+    for layer in layers:
+        w_t = PF.kernel_layout(layer.w.detach())
+        multi = PF.pack_weights(w_t, layer._spec, B, version=layer.w._version)
+        single = PF.pack_weights(w_t, layer._spec, B)
+        assert multi is not single and torch.equal(multi, single)
+    # a weight update invalidates the buffer (version counter)
+    with torch.no_grad():
+        layers[0].w.mul_(2.0)
+    w_t = PF.kernel_layout(layers[0].w.detach())
+    again = PF.pack_weights(w_t, layers[0]._spec, B, version=layers[0].w._version)
+    assert not torch.equal(again, multi)
+    assert (w_t.data_ptr(), layers[0].w._version) not in PF._prepacked
+    # through the network: same output with and without the batched pre-pack
+    net = NW.HighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=32, hidden_layers=2,
+                          hidden_width=64, in_segments=8, out_segments=2, hidden_segments=2,
+                          normalization=L.LazyLayerNormLastDim, device="cuda")
+    x = torch.rand(512, 16, device="cuda") * 2 - 1
+    y1 = net(x)
+    PF._prepacked.clear()
+    y2 = net.model(x)
+    assert torch.allclose(y1, y2, rtol=0, atol=2e-6 * y2.abs().max().item())
