@@ -62,7 +62,8 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds
 
 
-def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=20):
+def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=20,
+               prepacked=False):
     """Seconds per launch of the three entry points of one layer (auto methods, preallocated
     outputs and workspaces: the timed region is exactly the library's launches)."""
     from language_interpolation_amd import _lib
@@ -103,6 +104,20 @@ def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=
                                    1.0, 0, st)
 
     methods = [lib.pp_auto_method(p, B, I, O, n, S, d, 2.0) for p in range(3)]
+    if prepacked and methods[0] == _lib.FWD_FP16X2 and methods[1] == _lib.BWD_X_FP16X2:
+        # the way a training step runs them: weights pre-split once per step
+        # (pp_pack_weights_multi_f32), forward and backward-input are one kernel each
+        packed = PF.pack_weights(w_t, spec, B)
+        pk = packed.numel()
+        PRE = 0x100  # PP_WS_PREPACKED
+
+        def fwd():  # noqa: F811
+            lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(packed), pk, B, I, O, n, S, d, 2.0,
+                                  nodes, 1.0, _lib.FWD_FP16X2 | PRE, st)
+
+        def bwd_x():  # noqa: F811
+            lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(packed), pk, B, I, O, n, S,
+                                         d, 2.0, nodes, 1.0, _lib.BWD_X_FP16X2 | PRE, st)
     times = {"fwd": time_kernel(fwd, iters), "bwd_w": time_kernel(bwd_w, iters)}
     if not first:
         times["bwd_x"] = time_kernel(bwd_x, iters)
@@ -113,13 +128,13 @@ def roofline_for_hidden_layer(B, dev):
     """Times the three kernels of one hidden layer (continuous n=3 250->250 S=2) and
     reports the roofline of the one that takes longest."""
     n, S, I, O = 3, 2, 250, 250
-    t, methods, K = time_layer(B, False, n, S, I, O, dev)
+    t, methods, K = time_layer(B, False, n, S, I, O, dev, prepacked=True)
     fname = {1: "pp_fwd_gather_kernel", 2: "pp_fwd_dense_kernel",
              3: "pp_fwd_bf3_kernel<bf16x3>(+pack)",
-             4: "pp_fwd_bf3_kernel<fp16x2>(+absmax,+pack)", 5: "pp_fwd_slab_kernel"}[methods[0]]
+             4: "pp_fwd_bf3_kernel<fp16x2>", 5: "pp_fwd_slab_kernel"}[methods[0]]
     xname = {1: "pp_bwd_input_gather_kernel", 2: "pp_bwd_input_dense_kernel",
              3: "pp_bwd_x_bf3_kernel<bf16x3>(+pack)",
-             4: "pp_bwd_x_bf3_kernel<fp16x2>(+absmax,+pack)"}[methods[1]]
+             4: "pp_bwd_x_bf3_kernel<fp16x2>"}[methods[1]]
     wname = {1: "pp_bwd_weight_atomic_kernel", 2: "pp_bwd_weight_segreduce_kernel(+sort)",
              3: "pp_bwd_weight_dense_kernel(+reduce)",
              4: "pp_bwd_w_bf3_kernel<bf16x3>(+pack,+reduce)",
@@ -142,6 +157,8 @@ def roofline_for_hidden_layer(B, dev):
             traffic = measured["traffic_bytes"]
         elif name == xname and methods[1] == 4:
             traffic = measured["backward_input"]["traffic_bytes"]
+        elif name == fname and methods[0] == 4 and "forward" in measured:
+            traffic = measured["forward"]["traffic_bytes"]
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
@@ -152,7 +169,8 @@ def roofline_for_hidden_layer(B, dev):
         "arith": "fp16 MFMA on 2-way split fp32 operands (3 cross terms, ~22 significant bits), "
                  "fp32 accumulate; `peak` is the fp32 matrix peak the fp32 contract is priced "
                  "against -- the kernel issues 5x the algorithmic flops as fp16 MFMAs "
-                 "(3 cross terms x K/n = 5/3 dense padding)",
+                 "(3 cross terms x K/n = 5/3 dense padding); forward and backward-input timed on "
+                 "weights pre-split once per step (pp_pack_weights_multi_f32), as the step runs them",
     }
 
 
