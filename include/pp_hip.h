@@ -260,6 +260,18 @@ int pp_selective_scan_bwd_f32(const float* u, const float* delta, const float* A
  * length (the reference accepts every input_scale, networks.py:386-425) takes the gather path. */
 int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous, float length);
 
+/* Lion / SparseLion optimizer step (`optimizer=lion` / `sparse_lion` of the reference's configs:
+ * the yaml files under /root/reference/config/optimizer, built at networks.py:183-190 from
+ * lion_pytorch.Lion and high-order-layers-torch's SparseLion) for `count` <= PP_OPT_MAX_TENSORS
+ * parameters in one launch:  u = sign(b1*m + (1-b1)*g);  p = p*(1 - lr*wd) - lr*u;
+ * m = b2*m + (1-b2)*g;  sparse != 0: entries with g == 0 keep p (up to the decay) and m.
+ * p / g / m: device pointers to `numel[t]` floats each, same element order (storage order of the
+ * parameter), updated in place.  Host arrays of `count` entries. */
+#define PP_OPT_MAX_TENSORS 32
+int pp_lion_step_f32(int count, float* const* p, const float* const* g, float* const* m,
+                     const long* numel, float lr, float beta1, float beta2, float weight_decay,
+                     int sparse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpphip.so")
 PP_MAX_N = 8
 NOALLOC_SCRATCH_BYTES = 8 << 20
 PACK_MAX_LAYERS = 16
+OPT_MAX_TENSORS = 32
 
 # method ids (include/pp_hip.h)
 METHOD_AUTO = 0
@@ -57,6 +58,7 @@ SIGNATURES = {
     "pp_packed_weights_bytes": (c_size_t, [c_int] * 5 + [c_float]),
     "pp_pack_weights_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pp_pack_weights_multi_f32": (c_int, [c_int] + [_P] * 10),
+    "pp_lion_step_f32": (c_int, [c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P]),
     "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_input_ws_f32": (
         c_int,

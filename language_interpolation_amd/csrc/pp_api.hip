@@ -515,4 +515,18 @@ int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, i
   return hip_rc(pp_launch_max_abs_bwd(x, gy, gx, B, D, eps, (hipStream_t)stream));
 }
 
+int pp_lion_step_f32(int count, float* const* p, const float* const* g, float* const* m,
+                     const long* numel, float lr, float beta1, float beta2, float weight_decay,
+                     int sparse, void* stream) {
+  if (count < 1 || count > PP_OPT_MAX_TENSORS) return PP_ERR_SHAPE;
+  if (!p || !g || !m || !numel) return PP_ERR_NULL;
+  for (int t = 0; t < count; ++t) {
+    if (!p[t] || !g[t] || !m[t]) return PP_ERR_NULL;
+    if (numel[t] < 1) return PP_ERR_SHAPE;
+    if ((((size_t)p[t]) | ((size_t)g[t]) | ((size_t)m[t])) & 3) return PP_ERR_ALIGN;
+  }
+  return hip_rc(pp_launch_lion(count, p, g, m, numel, lr, beta1, beta2, weight_decay, sparse,
+                               (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -72,6 +72,10 @@ hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float e
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
 
+hipError_t pp_launch_lion(int count, float* const* p, const float* const* g, float* const* m,
+                          const long* numel, float lr, float b1, float b2, float wd, int sparse,
+                          hipStream_t st);
+
 // ---- Mamba selective scan (pp_scan.hip) ----
 hipError_t pp_launch_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
                               const float* Cm, const float* D, float* y, float* xhist, int b, int l,

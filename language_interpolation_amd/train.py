@@ -187,18 +187,60 @@ def select_network(cfg: Config, device=None) -> nn.Module:
 # optimizers the reference's configs name (lion_pytorch.Lion, high-order-layers-torch's
 # SparseLion: Lion that leaves entries with a zero gradient untouched)
 # ---------------------------------------------------------------------------
+def _dense_non_overlapping(t: torch.Tensor) -> bool:
+    """The tensor's elements fill numel() consecutive storage slots (any permutation of a
+    contiguous tensor does)."""
+    dims = sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1)
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
 class Lion(torch.optim.Optimizer):
-    """update = sign(b1*m + (1-b1)*g); p -= lr*(update + wd*p); m = b2*m + (1-b2)*g."""
+    """update = sign(b1*m + (1-b1)*g); p -= lr*(update + wd*p); m = b2*m + (1-b2)*g.
+    On the GPU the whole step of a parameter group is one kernel (pp_lion_step_f32); the torch
+    expressions below are the same rule for tensors it does not take (CPU, other dtypes)."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0, sparse=False):
         super().__init__(params, dict(lr=lr, betas=betas, weight_decay=weight_decay))
         self.sparse = sparse
+
+    @staticmethod
+    def _fusable(p, g, m) -> bool:
+        """One flat pass in storage order: same dense layout for all three (the layers'
+        parameters are permuted leaves; their gradients and zeros_like momenta share the strides)."""
+        return (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32
+                and g.layout == torch.strided and p.stride() == g.stride() == m.stride()
+                and _dense_non_overlapping(p))
+
+    def _fused_step(self, todo, lr, b1, b2, wd):
+        """pp_lion_step_f32: all parameters of a group in one launch (per PP_OPT_MAX_TENSORS)."""
+        import ctypes
+        from . import _lib
+        from .functional import _stream
+        lib = _lib.load()
+        for lo in range(0, len(todo), _lib.OPT_MAX_TENSORS):
+            part = todo[lo:lo + _lib.OPT_MAX_TENSORS]
+            cnt = len(part)
+            with torch.cuda.device(part[0][0].device):
+                rc = lib.pp_lion_step_f32(
+                    cnt,
+                    (ctypes.c_void_p * cnt)(*[p.data_ptr() for p, _, _ in part]),
+                    (ctypes.c_void_p * cnt)(*[g.data_ptr() for _, g, _ in part]),
+                    (ctypes.c_void_p * cnt)(*[m.data_ptr() for _, _, m in part]),
+                    (ctypes.c_long * cnt)(*[p.numel() for p, _, _ in part]),
+                    lr, b1, b2, wd, int(self.sparse), _stream(part[0][0].device))
+            _lib.check(rc, "pp_lion_step_f32")
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             lr, (b1, b2), wd = group["lr"], group["betas"], group["weight_decay"]
+            fused = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -207,6 +249,9 @@ class Lion(torch.optim.Optimizer):
                 if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p)
                 m = st["exp_avg"]
+                if self._fusable(p, g, m):
+                    fused.append((p, g, m))
+                    continue
                 update = (m * b1).add_(g, alpha=1 - b1).sign_()
                 new_m = (m * b2).add_(g, alpha=1 - b2)
                 if self.sparse:  # weights no sample touched keep value and momentum
@@ -217,6 +262,8 @@ class Lion(torch.optim.Optimizer):
                     p.mul_(1 - lr * wd)
                 p.add_(update, alpha=-lr)
                 m.copy_(new_m)
+            if fused:
+                self._fused_step(fused, lr, b1, b2, wd)
         return loss
 
 

@@ -160,3 +160,39 @@ def test_char_windows_and_sequences_are_exact_on_the_device():
     want_x = torch.stack([codes[i:i + F - 1] for i in ic.tolist()]).long()
     want_y = torch.stack([codes[i + 1:i + F] for i in ic.tolist()]).long()
     assert torch.equal(xs.cpu()[:, :, 0], want_x) and torch.equal(ys.cpu()[:, :, 0], want_y)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_fused_lion_step_matches_the_torch_rule(sparse):
+    """pp_lion_step_f32 (one launch for all parameters, storage order) against the same rule in
+    torch ops on CPU copies: permuted layer parameters, an odd-sized tensor, weight decay, zero
+    gradients (SparseLion leaves those entries and their momentum alone), two steps."""
+    from language_interpolation_amd import train as T
+    torch.manual_seed(5)
+    shapes = [(250, 16, 129), (7, 3, 5), (33,), (128, 250, 5)]
+    cpu_p, gpu_p = [], []
+    for sh in shapes:
+        base = torch.randn(*sh)
+        if len(sh) == 3:   # physical [I,K,O], logical [O,I,K]: what the layers hold
+            phys = base.permute(1, 2, 0).contiguous()
+            cp = phys.clone().permute(2, 0, 1)
+            gp = phys.clone().cuda().permute(2, 0, 1)
+        else:
+            cp, gp = base.clone(), base.clone().cuda()
+        cpu_p.append(torch.nn.Parameter(cp))
+        gpu_p.append(torch.nn.Parameter(gp))
+    opt_c = T.Lion(cpu_p, lr=3e-3, betas=(0.9, 0.99), weight_decay=0.1, sparse=sparse)
+    opt_g = T.Lion(gpu_p, lr=3e-3, betas=(0.9, 0.99), weight_decay=0.1, sparse=sparse)
+    assert all(T.Lion._fusable(p, torch.zeros_like(p), torch.zeros_like(p)) for p in gpu_p)
+    for step in range(2):
+        for pc, pg in zip(cpu_p, gpu_p):
+            g = torch.randn(pc.shape)
+            g[torch.rand(pc.shape) < 0.3] = 0.0
+            pc.grad = g.clone()
+            pg.grad = torch.empty_like(pg).copy_(g)     # same strides as the parameter
+        opt_c.step()
+        opt_g.step()
+        for pc, pg in zip(cpu_p, gpu_p):
+            assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=0, atol=1e-6), step
+            mc, mg = opt_c.state[pc]["exp_avg"], opt_g.state[pg]["exp_avg"]
+            assert torch.allclose(mg.cpu(), mc, rtol=1e-6, atol=1e-7), step
