@@ -260,6 +260,38 @@ int pp_selective_scan_bwd_f32(const float* u, const float* delta, const float* A
  * length (the reference accepts every input_scale, networks.py:386-425) takes the gather path. */
 int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous, float length);
 
+/* The pieces of the reference's Mamba block around the projections and the scan
+ * (/root/reference/language_interpolation/state_space_network.py), one kernel per direction each.
+ * Channels (d) are contiguous; `ldx` / `ldr` are row strides in floats of inputs that are column
+ * slices of a wider tensor (x and res are the two halves of in_proj's output, :311-313).
+ *
+ * Causal depthwise conv1d + SiLU (:315-324: conv1d(x^T)[:, :, :l]^T then F.silu), x [b,l,d],
+ * w [d,k] (nn.Conv1d's [d,1,k]), bias [d] or NULL, k <= 8:
+ *   conv[b,t,c] = bias[c] + sum_j w[c,j] * x[b, t-(k-1)+j, c]   (kept for the backward)
+ *   y = silu(conv).
+ * Backward: gx [b,l,d] contiguous, gw [d,k], gbias [d] or NULL; per-chunk partial sums in the
+ * workspace, summed in a fixed order (no atomics). */
+size_t pp_causal_conv_silu_bwd_workspace_bytes(int b, int d);
+int pp_causal_conv_silu_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                                float* conv, float* y, int b, int l, int d, int k, void* stream);
+int pp_causal_conv_silu_bwd_f32(const float* x, int ldx, const float* w, const float* conv,
+                                const float* gy, float* gx, float* gw, float* gbias,
+                                void* workspace, size_t workspace_bytes, int b, int l, int d, int k,
+                                void* stream);
+/* The gate y = s * silu(r) (:326) and its backward (gs, gr contiguous [rows,d]). */
+int pp_silu_gate_fwd_f32(const float* s, const float* r, int ldr, float* y, long rows, int d,
+                         void* stream);
+int pp_silu_gate_bwd_f32(const float* s, const float* r, int ldr, const float* gy, float* gs,
+                         float* gr, long rows, int d, void* stream);
+/* RMSNorm (:423-433): y = x * rsqrt(mean(x^2) + eps) * weight, rstd[rows] kept for the backward;
+ * gx, gweight [D] (per-wave partial sums in the workspace, fixed order).  D <= 1024. */
+size_t pp_rms_norm_bwd_workspace_bytes_f32(long rows, int D);
+int pp_rms_norm_fwd_f32(const float* x, const float* weight, float* y, float* rstd, long rows,
+                        int D, float eps, void* stream);
+int pp_rms_norm_bwd_f32(const float* x, const float* weight, const float* rstd, const float* gy,
+                        float* gx, float* gweight, void* workspace, size_t workspace_bytes,
+                        long rows, int D, void* stream);
+
 /* Lion / SparseLion optimizer step (`optimizer=lion` / `sparse_lion` of the reference's configs:
  * the yaml files under /root/reference/config/optimizer, built at networks.py:183-190 from
  * lion_pytorch.Lion and high-order-layers-torch's SparseLion) for `count` <= PP_OPT_MAX_TENSORS

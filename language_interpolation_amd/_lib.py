@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpphip.so")
@@ -58,6 +58,15 @@ SIGNATURES = {
     "pp_packed_weights_bytes": (c_size_t, [c_int] * 5 + [c_float]),
     "pp_pack_weights_f32": (c_int, [_P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "pp_pack_weights_multi_f32": (c_int, [c_int] + [_P] * 10),
+    "pp_causal_conv_silu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pp_causal_conv_silu_fwd_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pp_causal_conv_silu_bwd_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t,
+                                            c_int, c_int, c_int, c_int, _P]),
+    "pp_silu_gate_fwd_f32": (c_int, [_P, _P, c_int, _P, c_long, c_int, _P]),
+    "pp_silu_gate_bwd_f32": (c_int, [_P, _P, c_int, _P, _P, _P, c_long, c_int, _P]),
+    "pp_rms_norm_bwd_workspace_bytes_f32": (c_size_t, [c_long, c_int]),
+    "pp_rms_norm_fwd_f32": (c_int, [_P, _P, _P, _P, c_long, c_int, c_float, _P]),
+    "pp_rms_norm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_long, c_int, _P]),
     "pp_lion_step_f32": (c_int, [c_int, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P]),
     "pp_backward_input_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_input_ws_f32": (

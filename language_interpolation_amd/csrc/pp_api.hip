@@ -515,6 +515,82 @@ int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, i
   return hip_rc(pp_launch_max_abs_bwd(x, gy, gx, B, D, eps, (hipStream_t)stream));
 }
 
+static int mamba_dims_ok(long rows, int d) {
+  if (rows < 1 || d < 1) return PP_ERR_SHAPE;
+  if (rows * d >= (1L << 31)) return PP_ERR_RANGE;
+  return PP_OK;
+}
+
+size_t pp_causal_conv_silu_bwd_workspace_bytes(int b, int d) {
+  return b > 0 && d > 0 ? pp_conv_silu_bwd_workspace_bytes(b, d) : 0;
+}
+
+int pp_causal_conv_silu_fwd_f32(const float* x, int ldx, const float* w, const float* bias,
+                                float* conv, float* y, int b, int l, int d, int k, void* stream) {
+  if (!x || !w || !conv || !y) return PP_ERR_NULL;
+  if (b < 1 || l < 1 || k < 1 || k > 8 || ldx < d) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok((long)b * l, std::max(d, ldx));
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_conv_silu_fwd(x, ldx, w, bias, conv, y, b, l, d, k, (hipStream_t)stream));
+}
+
+int pp_causal_conv_silu_bwd_f32(const float* x, int ldx, const float* w, const float* conv,
+                                const float* gy, float* gx, float* gw, float* gbias,
+                                void* workspace, size_t workspace_bytes, int b, int l, int d, int k,
+                                void* stream) {
+  if (!x || !w || !conv || !gy || !gx || !gw) return PP_ERR_NULL;
+  if (b < 1 || l < 1 || k < 1 || k > 8 || ldx < d) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok((long)b * l, std::max(d, ldx));
+  if (rc != PP_OK) return rc;
+  if (!workspace || workspace_bytes < pp_conv_silu_bwd_workspace_bytes(b, d)) return PP_ERR_WORKSPACE;
+  return hip_rc(pp_launch_conv_silu_bwd(x, ldx, w, conv, gy, gx, gw, gbias, workspace, b, l, d, k,
+                                        (hipStream_t)stream));
+}
+
+int pp_silu_gate_fwd_f32(const float* s, const float* r, int ldr, float* y, long rows, int d,
+                         void* stream) {
+  if (!s || !r || !y) return PP_ERR_NULL;
+  if (ldr < d) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok(rows, std::max(d, ldr));
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_silu_gate_fwd(s, r, ldr, y, rows, d, (hipStream_t)stream));
+}
+
+int pp_silu_gate_bwd_f32(const float* s, const float* r, int ldr, const float* gy, float* gs,
+                         float* gr, long rows, int d, void* stream) {
+  if (!s || !r || !gy || !gs || !gr) return PP_ERR_NULL;
+  if (ldr < d) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok(rows, std::max(d, ldr));
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_silu_gate_bwd(s, r, ldr, gy, gs, gr, rows, d, (hipStream_t)stream));
+}
+
+size_t pp_rms_norm_bwd_workspace_bytes_f32(long rows, int D) {
+  return rows > 0 && D > 0 ? pp_rms_norm_bwd_workspace_bytes(rows, D) : 0;
+}
+
+int pp_rms_norm_fwd_f32(const float* x, const float* weight, float* y, float* rstd, long rows,
+                        int D, float eps, void* stream) {
+  if (!x || !weight || !y || !rstd) return PP_ERR_NULL;
+  if (D > 1024) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok(rows, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_rms_norm_fwd(x, weight, y, rstd, rows, D, eps, (hipStream_t)stream));
+}
+
+int pp_rms_norm_bwd_f32(const float* x, const float* weight, const float* rstd, const float* gy,
+                        float* gx, float* gweight, void* workspace, size_t workspace_bytes,
+                        long rows, int D, void* stream) {
+  if (!x || !weight || !rstd || !gy || !gx || !gweight) return PP_ERR_NULL;
+  if (D > 1024) return PP_ERR_SHAPE;
+  int rc = mamba_dims_ok(rows, D);
+  if (rc != PP_OK) return rc;
+  if (!workspace || workspace_bytes < pp_rms_norm_bwd_workspace_bytes(rows, D))
+    return PP_ERR_WORKSPACE;
+  return hip_rc(pp_launch_rms_norm_bwd(x, weight, rstd, gy, gx, gweight, workspace, rows, D,
+                                       (hipStream_t)stream));
+}
+
 int pp_lion_step_f32(int count, float* const* p, const float* const* g, float* const* m,
                      const long* numel, float lr, float beta1, float beta2, float weight_decay,
                      int sparse, void* stream) {

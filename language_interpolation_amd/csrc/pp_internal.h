@@ -85,6 +85,25 @@ hipError_t pp_launch_scan_bwd(const float* u, const float* delta, const float* A
                               float* gu, float* gdelta, float* gA_t, float* gB, float* gC, float* gD,
                               int b, int l, int d, int n, hipStream_t st);
 
+// ---- Mamba block pieces around the projections and the scan (pp_mamba.hip) ----
+size_t pp_conv_silu_bwd_workspace_bytes(int b, int d);
+size_t pp_rms_norm_bwd_workspace_bytes(long rows, int D);
+hipError_t pp_launch_conv_silu_fwd(const float* x, int ldx, const float* w, const float* bias,
+                                   float* conv, float* y, int b, int l, int d, int k,
+                                   hipStream_t st);
+hipError_t pp_launch_conv_silu_bwd(const float* x, int ldx, const float* w, const float* conv,
+                                   const float* gy, float* gx, float* gw, float* gb, void* ws,
+                                   int b, int l, int d, int k, hipStream_t st);
+hipError_t pp_launch_silu_gate_fwd(const float* s, const float* r, int ldr, float* y, long rows,
+                                   int d, hipStream_t st);
+hipError_t pp_launch_silu_gate_bwd(const float* s, const float* r, int ldr, const float* gy,
+                                   float* gs, float* gr, long rows, int d, hipStream_t st);
+hipError_t pp_launch_rms_norm_fwd(const float* x, const float* w, float* y, float* rstd, long rows,
+                                  int D, float eps, hipStream_t st);
+hipError_t pp_launch_rms_norm_bwd(const float* x, const float* w, const float* rstd,
+                                  const float* gy, float* gx, float* gw, void* ws, long rows, int D,
+                                  hipStream_t st);
+
 // ---- dense path on bf16 MFMA with a 3-way fp32 split (pp_bf3_fwd.hip, pp_bf3_bwdx.hip, pp_bf3_bwdw.hip; shared: pp_bf3_common.h) ----
 bool pp_bf3_supported(const PPShape& sh);
 size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh);

@@ -524,3 +524,157 @@ class SelectiveScanFunction(torch.autograd.Function):
 def selective_scan(u, delta, A, Bm, Cm, D):
     """y [b,l,d] from u, delta [b,l,d], A [d,n], B, C [b,l,n], D [d] (GPU fp32 only)."""
     return SelectiveScanFunction.apply(u, delta, A, Bm, Cm, D)
+
+
+# ---------------------------------------------------------------------------
+# The Mamba block's pieces around the projections and the scan (csrc/pp_mamba.hip)
+# ---------------------------------------------------------------------------
+def _rows_view(t: torch.Tensor):
+    """(tensor usable in place, rows, d, row stride): a [..., d] tensor whose last dim is
+    contiguous and whose leading dims collapse to rows with one stride -- e.g. a column slice of
+    a contiguous [..., 2d] tensor -- is passed as is; anything else is made contiguous."""
+    d = t.shape[-1]
+    if t.dim() >= 2 and t.stride(-1) == 1:
+        ld = t.stride(-2)
+        ok = ld >= d
+        for i in range(t.dim() - 2):
+            ok = ok and t.stride(i) == t.stride(i + 1) * t.shape[i + 1]
+        if ok:
+            return t, t.numel() // d, d, ld
+    t = t.contiguous()
+    return t, t.numel() // d, d, d
+
+
+class CausalConvSiluFunction(torch.autograd.Function):
+    """silu(causal depthwise conv1d(x) + bias) on [b, l, d] (state_space_network.py:315-324)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        b, l, d = x.shape
+        k = weight.shape[-1]
+        x, _, _, ldx = _rows_view(x.float())
+        w = weight.reshape(d, k).contiguous().float()
+        bs = bias.contiguous().float() if bias is not None else None
+        conv = torch.empty(b, l, d, device=x.device, dtype=torch.float32)
+        y = torch.empty_like(conv)
+        if conv.numel():
+            with torch.cuda.device(x.device):
+                rc = lib.pp_causal_conv_silu_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(bs), _ptr(conv),
+                                                     _ptr(y), b, l, d, k, _stream(x.device))
+            _lib.check(rc, "pp_causal_conv_silu_fwd_f32")
+        ctx.save_for_backward(x, w, conv)
+        ctx.meta = (ldx, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w, conv = ctx.saved_tensors
+        ldx, has_bias, wshape = ctx.meta
+        b, l, d = conv.shape
+        k = w.shape[1]
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(conv)
+        gw = torch.empty_like(w)
+        gb = torch.empty(d, device=w.device, dtype=torch.float32) if has_bias else None
+        if conv.numel():
+            nbytes = lib.pp_causal_conv_silu_bwd_workspace_bytes(b, d)
+            ws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+            with torch.cuda.device(w.device):
+                rc = lib.pp_causal_conv_silu_bwd_f32(_ptr(x), ldx, _ptr(w), _ptr(conv), _ptr(gy),
+                                                     _ptr(gx), _ptr(gw), _ptr(gb), _ptr(ws), nbytes,
+                                                     b, l, d, k, _stream(w.device))
+            _lib.check(rc, "pp_causal_conv_silu_bwd_f32")
+        return gx, gw.reshape(wshape), gb
+
+
+def causal_conv_silu(x, weight, bias=None):
+    return CausalConvSiluFunction.apply(x, weight, bias)
+
+
+class SiluGateFunction(torch.autograd.Function):
+    """y = s * silu(r) (state_space_network.py:326)."""
+
+    @staticmethod
+    def forward(ctx, s, r):
+        lib = _lib.load()
+        _require_gpu(s, "s")
+        s = s.contiguous().float()
+        r, rows, d, ldr = _rows_view(r.float())
+        y = torch.empty_like(s)
+        if y.numel():
+            with torch.cuda.device(s.device):
+                rc = lib.pp_silu_gate_fwd_f32(_ptr(s), _ptr(r), ldr, _ptr(y), rows, d,
+                                              _stream(s.device))
+            _lib.check(rc, "pp_silu_gate_fwd_f32")
+        ctx.save_for_backward(s, r)
+        ctx.meta = (rows, d, ldr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        s, r = ctx.saved_tensors
+        rows, d, ldr = ctx.meta
+        gy = gy.contiguous().float()
+        gs = torch.empty_like(s)
+        gr = torch.empty(r.shape, device=s.device, dtype=torch.float32)
+        if gs.numel():
+            with torch.cuda.device(s.device):
+                rc = lib.pp_silu_gate_bwd_f32(_ptr(s), _ptr(r), ldr, _ptr(gy), _ptr(gs), _ptr(gr),
+                                              rows, d, _stream(s.device))
+            _lib.check(rc, "pp_silu_gate_bwd_f32")
+        return gs, gr
+
+
+def silu_gate(s, r):
+    return SiluGateFunction.apply(s, r)
+
+
+class RMSNormFunction(torch.autograd.Function):
+    """x * rsqrt(mean(x^2) + eps) * weight over the last dim (state_space_network.py:423-433)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        x2, D = _rows(x.float())
+        if D > NORM_MAX_D:
+            raise ValueError(f"rms_norm: last dim {D} > {NORM_MAX_D}")
+        w = weight.contiguous().float()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        if x2.numel():
+            with torch.cuda.device(x.device):
+                rc = lib.pp_rms_norm_fwd_f32(_ptr(x2), _ptr(w), _ptr(y), _ptr(rstd), rows, D, eps,
+                                             _stream(x.device))
+            _lib.check(rc, "pp_rms_norm_fwd_f32")
+        ctx.save_for_backward(x2, w, rstd)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x2, w, rstd = ctx.saved_tensors
+        rows, D = x2.shape
+        gy2 = gy.reshape(rows, D).contiguous().float()
+        gx = torch.empty_like(x2)
+        gw = torch.empty_like(w)
+        if x2.numel():
+            nbytes = lib.pp_rms_norm_bwd_workspace_bytes_f32(rows, D)
+            ws = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+            with torch.cuda.device(w.device):
+                rc = lib.pp_rms_norm_bwd_f32(_ptr(x2), _ptr(w), _ptr(rstd), _ptr(gy2), _ptr(gx),
+                                             _ptr(gw), _ptr(ws), nbytes, rows, D, _stream(w.device))
+            _lib.check(rc, "pp_rms_norm_bwd_f32")
+        else:
+            gw.zero_()
+        return gx.reshape(ctx.shape), gw, None
+
+
+def rms_norm(x, weight, eps: float = 1e-5):
+    return RMSNormFunction.apply(x, weight, eps)

@@ -5,8 +5,9 @@ arguments, module / parameter names (``embedding``, ``layers.<i>.mixer.{in_proj,
 dt_proj,A_log,D,out_proj}``, ``layers.<i>.norm.weight``, ``norm_f.weight``, tied ``lm_head``)
 and tensor shapes.  The four projections of a block are ``HighOrderMLP`` (two piecewise-
 polynomial layers each: the hot path) unless ``layer_type == "linear"``; the time loop of
-``selective_scan`` (:372-420) is one HIP kernel per direction (csrc/pp_scan.hip).  Embedding,
-SiLU / softplus and RMSNorm stay torch ops; the depthwise conv is k shifted multiply-adds.
+``selective_scan`` (:372-420) is one HIP kernel per direction (csrc/pp_scan.hip); the causal
+depthwise conv + SiLU, the gate ``y * silu(res)`` and RMSNorm are one HIP kernel per direction
+each (csrc/pp_mamba.hip).  Embedding, softplus and lm_head stay torch ops (one kernel each).
 """
 from __future__ import annotations
 
@@ -54,7 +55,7 @@ class RMSNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(d_model))
 
     def forward(self, x):
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+        return PF.rms_norm(x, self.weight, self.eps)
 
 
 class MambaBlock(nn.Module):
@@ -78,8 +79,8 @@ class MambaBlock(nn.Module):
 
     def forward(self, x):
         x, res = reshape_apply(x, self.in_proj).split([self.d_inner, self.d_inner], dim=-1)
-        x = causal_depthwise_conv(x, self.conv1d.weight, self.conv1d.bias)
-        y = self.ssm(F.silu(x)) * F.silu(res)
+        x = PF.causal_conv_silu(x, self.conv1d.weight, self.conv1d.bias)
+        y = PF.silu_gate(self.ssm(x), res)
         return reshape_apply(y, self.out_proj)
 
     def ssm(self, x):

@@ -102,3 +102,54 @@ def test_mamba_matches_oracle_forward_and_gradients(layer_type):
         r = src[key].grad
         assert p.grad is not None, name
         assert (p.grad.double().cpu() - r).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-9, name
+
+
+@pytest.mark.parametrize("b,l,d,k,bias", [(64, 15, 128, 4, True), (3, 7, 100, 2, False),
+                                          (1030, 5, 64, 4, True), (2, 1, 70, 3, True)])
+def test_block_pieces_match_the_torch_formulation(b, l, d, k, bias):
+    """Conv + SiLU, the gate and RMSNorm kernels (csrc/pp_mamba.hip) against the torch
+    expressions of state_space_network.py:315-326 / :423-433 in fp64, values and every gradient;
+    x and res are the two halves of one tensor, as in the block."""
+    import torch.nn.functional as F
+    from language_interpolation_amd import functional as PF
+    from language_interpolation_amd.mamba import causal_depthwise_conv
+    g = torch.Generator().manual_seed(b + l + d)
+    both = torch.randn(b, l, 2 * d, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(d, 1, k, generator=g) * 0.5).cuda().requires_grad_(True)
+    bs = torch.randn(d, generator=g).cuda().requires_grad_(True) if bias else None
+    nw = (torch.rand(d, generator=g) + 0.5).cuda().requires_grad_(True)
+    gy = torch.randn(b, l, d, generator=g).cuda()
+
+    def run(fused, leaves):
+        bt, wt, bst, nwt = leaves
+        x, res = bt.split([d, d], dim=-1)
+        if fused:
+            c = PF.causal_conv_silu(x, wt, bst)
+            y = PF.silu_gate(c, res)
+            return PF.rms_norm(y, nwt, 1e-5)
+        c = F.silu(causal_depthwise_conv(x, wt, bst))
+        y = c * F.silu(res)
+        return y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-5) * nwt
+
+    out = run(True, (both, w, bs, nw))
+    out.backward(gy)
+    ref_leaves = [t.detach().double().requires_grad_(True) if t is not None else None
+                  for t in (both, w, bs, nw)]
+    ref = run(False, ref_leaves)
+    ref.backward(gy.double())
+
+    def close(a, r, what):
+        err = (a.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        assert err <= 2e-5, (what, err)
+
+    close(out, ref, "y")
+    close(both.grad, ref_leaves[0].grad, "gx/gres")
+    close(w.grad, ref_leaves[1].grad, "gw")
+    if bias:
+        close(bs.grad, ref_leaves[2].grad, "gbias")
+    close(nw.grad, ref_leaves[3].grad, "gnorm")
+    # fixed summation order: the same bits on a second run
+    both.grad = w.grad = nw.grad = None
+    out2 = run(True, (both, w, bs, nw))
+    out2.backward(gy)
+    assert torch.equal(out2, out)
