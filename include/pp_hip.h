@@ -237,6 +237,24 @@ int pp_max_abs_norm_fwd_f32(const float* x, float* y, int B, int D, float eps, v
 int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, int D, float eps,
                             void* stream);
 
+/* Forward of a layer with the FOLLOWING MaxAbsNormalizationLast fused into the gather kernel's
+ * epilogue (HighOrderMLP with normalization=MaxAbsNormalizationLast, networks.py:58-59 and
+ * :866-882): y = layer(x) / (max|layer(x)| + eps), bit-identical to pp_forward_f32(PP_FWD_GATHER)
+ * + pp_max_abs_norm_fwd_f32; the raw layer output is never stored.  den[B] receives the
+ * denominators and amax[B] the first index attaining each row's maximum;
+ * pp_max_abs_norm_bwd_y_f32 is the backward from those and the NORMALISED row:
+ *   gx_j = (gy_j - [j == amax] * sign(y_amax) * sum_k gy_k y_k) / den.
+ * n <= 4, 4 <= O <= 1024.  pp_forward_max_abs_supported: 2 when this is what a caller should run
+ * for the shape (a layer the gather kernels serve), else 0 -- the matrix-core forward has no
+ * max-abs epilogue (no configuration of the reference's README uses this normalisation). */
+int pp_forward_max_abs_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                 float length);
+int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,
+                           int B, int I, int O, int n, int S, int discontinuous, float length,
+                           const float* nodes, float out_scale, float eps, void* stream);
+int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
+                              const int32_t* amax, float* gx, int B, int D, void* stream);
+
 /* Selective scan of the reference's Mamba block (state_space_network.py:372-420: the Python
  * loop over the sequence in MambaBlock.selective_scan):
  *   x_t = exp(delta_t * A) * x_{t-1} + delta_t * B_t * u_t ;  y_t = <C_t, x_t> + D * u_t

@@ -451,6 +451,29 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
   return 0;
 }
 
+int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,
+                           int B, int I, int O, int n, int S, int discontinuous, float length,
+                           const float* nodes, float out_scale, float eps, void* stream) {
+  if (!x || !w_t || !y || !den || !amax) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(w_t) || !aligned16(y)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (!pp_gather_ln_supported(sh)) return PP_ERR_METHOD;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_fwd_gather_maxabs(x, w_t, y, den, amax, sh, tab, eps,
+                                            (hipStream_t)stream));
+}
+
+int pp_forward_max_abs_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                 float length) {
+  PPShape sh;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
+  // the gather kernels' layers only: the matrix-core forward has no max-abs epilogue
+  return (!dense_preferred(sh) && pp_gather_ln_supported(sh)) ? 2 : 0;
+}
+
 static int scan_args_ok(int b, int l, int d, int n) {
   if (b < 1 || l < 1 || d < 1 || n < 1 || b > 65535) return PP_ERR_SHAPE;
   if ((long)b * l * d >= (1L << 31) || (long)b * l * n >= (1L << 31)) return PP_ERR_RANGE;
@@ -513,6 +536,15 @@ int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, i
   int rc = norm_args_ok(B, D);
   if (rc != PP_OK) return rc;
   return hip_rc(pp_launch_max_abs_bwd(x, gy, gx, B, D, eps, (hipStream_t)stream));
+}
+
+int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
+                              const int32_t* amax, float* gx, int B, int D, void* stream) {
+  if (!y || !gy || !den || !amax || !gx) return PP_ERR_NULL;
+  if (!aligned16(y) || !aligned16(gy) || !aligned16(gx)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, D);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_max_abs_bwd_y(y, gy, den, amax, gx, B, D, (hipStream_t)stream));
 }
 
 static int mamba_dims_ok(long rows, int d) {

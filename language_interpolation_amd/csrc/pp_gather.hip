@@ -105,12 +105,16 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restr
 // normalised in registers and the raw layer output never exists in memory.  Same order of the
 // sum over inputs as pp_fwd_gather_kernel and the same reductions as pp_layer_norm_fwd_kernel
 // (pp_norm.hip) at the same V: bit-identical to running the two kernels one after the other.
+// NORM = 1: MaxAbsNormalizationLast instead (networks.py:48-69 of the reference: y / (max|y| +
+// eps)); `rstd` then receives the denominator and `amax` the first index attaining the maximum,
+// which is all pp_max_abs_bwd_y_kernel (pp_norm.hip) needs besides the normalised row.
 // ---------------------------------------------------------------------------
-template <int N, int V, int CH>
+template <int N, int V, int CH, int NORM>
 __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wt,
                                                                float* __restrict__ y,
                                                                float* __restrict__ rstd,
+                                                               int32_t* __restrict__ amax,
                                                                PPShape sh, BasisTab tab, float eps) {
   constexpr int RW = (CH * V <= 8) ? 2 : 1;
   const int lane = threadIdx.x & 63;
@@ -170,6 +174,41 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     if (row0 + r >= sh.B) break;  // wave-uniform
+    if constexpr (NORM == 1) {
+      float m = 0.0f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          acc[r][c][v] = ok[c] ? acc[r][c][v] * sh.out_scale : 0.0f;
+          m = fmaxf(m, fabsf(acc[r][c][v]));
+        }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      int idx = 0x7fffffff;  // first index attaining the maximum
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (ok[c] && fabsf(acc[r][c][v]) == m) idx = min(idx, dcl[c] + v);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) idx = min(idx, __shfl_xor(idx, off, 64));
+      const float den = m + eps;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (ok[c]) {
+          PPVec<V> out;
+#pragma unroll
+          for (int v = 0; v < V; ++v) out.v[v] = acc[r][c][v] / den;
+          out.store(y + (size_t)(row0 + r) * sh.O + dcl[c]);
+        }
+      }
+      if (lane == 0) {
+        rstd[row0 + r] = den;
+        amax[row0 + r] = idx;
+      }
+      continue;
+    }
     float s = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -467,16 +506,17 @@ bool pp_gather_ln_supported(const PPShape& sh) {
 }
 
 namespace {
-template <int N>
-hipError_t fwd_ln_dispatch(const float* x, const float* wt, float* y, float* rstd,
+template <int N, int NORM>
+hipError_t fwd_ln_dispatch(const float* x, const float* wt, float* y, float* rstd, int32_t* amax,
                            const PPShape& sh, const BasisTab& tab, float eps, hipStream_t st) {
   int V, CH;
   if (!gather_ln_combo(sh.O, V, CH)) return hipErrorInvalidValue;
 #define PP_LN_CASE(V_, CH_)                                                                  \
   if (V == V_ && CH == CH_) {                                                                \
     constexpr int RW = (CH_ * V_ <= 8) ? 2 : 1;                                              \
-    hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_>), dim3((sh.B + 4 * RW - 1) / (4 * RW)), \
-                       dim3(256), 0, st, x, wt, y, rstd, sh, tab, eps);                      \
+    hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM>),                            \
+                       dim3((sh.B + 4 * RW - 1) / (4 * RW)), dim3(256), 0, st, x, wt, y, rstd, \
+                       amax, sh, tab, eps);                                                  \
     return hipGetLastError();                                                                \
   }
   PP_LN_CASE(4, 1) PP_LN_CASE(4, 2) PP_LN_CASE(4, 4)
@@ -491,10 +531,23 @@ hipError_t pp_launch_fwd_gather_ln(const float* x, const float* wt, float* y, fl
                                    const PPShape& sh, const BasisTab& tab, float eps,
                                    hipStream_t st) {
   switch (sh.n) {
-    case 1: return fwd_ln_dispatch<1>(x, wt, y, rstd, sh, tab, eps, st);
-    case 2: return fwd_ln_dispatch<2>(x, wt, y, rstd, sh, tab, eps, st);
-    case 3: return fwd_ln_dispatch<3>(x, wt, y, rstd, sh, tab, eps, st);
-    case 4: return fwd_ln_dispatch<4>(x, wt, y, rstd, sh, tab, eps, st);
+    case 1: return fwd_ln_dispatch<1, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
+    case 2: return fwd_ln_dispatch<2, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
+    case 3: return fwd_ln_dispatch<3, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
+    case 4: return fwd_ln_dispatch<4, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// the same with MaxAbsNormalizationLast as the epilogue: den[B] and amax[B] for the backward
+hipError_t pp_launch_fwd_gather_maxabs(const float* x, const float* wt, float* y, float* den,
+                                       int32_t* amax, const PPShape& sh, const BasisTab& tab,
+                                       float eps, hipStream_t st) {
+  switch (sh.n) {
+    case 1: return fwd_ln_dispatch<1, 1>(x, wt, y, den, amax, sh, tab, eps, st);
+    case 2: return fwd_ln_dispatch<2, 1>(x, wt, y, den, amax, sh, tab, eps, st);
+    case 3: return fwd_ln_dispatch<3, 1>(x, wt, y, den, amax, sh, tab, eps, st);
+    case 4: return fwd_ln_dispatch<4, 1>(x, wt, y, den, amax, sh, tab, eps, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -26,6 +26,9 @@ bool pp_gather_ln_supported(const PPShape& sh);  // fused LayerNorm epilogue: n 
 hipError_t pp_launch_fwd_gather_ln(const float* x, const float* wt, float* y, float* rstd,
                                    const PPShape& sh, const BasisTab& tab, float eps,
                                    hipStream_t st);
+hipError_t pp_launch_fwd_gather_maxabs(const float* x, const float* wt, float* y, float* den,
+                                       int32_t* amax, const PPShape& sh, const BasisTab& tab,
+                                       float eps, hipStream_t st);
 hipError_t pp_launch_bwd_input_gather(const float* x, const float* gy, const float* wt, float* gx,
                                       const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* gwt,
@@ -71,6 +74,8 @@ hipError_t pp_launch_layer_norm_bwd(const float* y, const float* gy, const float
 hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float eps, hipStream_t st);
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
+hipError_t pp_launch_max_abs_bwd_y(const float* y, const float* gy, const float* den,
+                                   const int32_t* amax, float* gx, int B, int D, hipStream_t st);
 
 hipError_t pp_launch_lion(int count, float* const* p, const float* const* g, float* const* m,
                           const long* numel, float lr, float b1, float b2, float wd, int sparse,

@@ -186,6 +186,41 @@ __global__ __launch_bounds__(256) void pp_max_abs_bwd_kernel(const float* __rest
   rg.store(gx + (size_t)row * D, D, lane);
 }
 
+// The same backward from what the fused layer+maxabs forward keeps (pp_fwd_gather_ln_kernel,
+// NORM = 1): the normalised row y = x/d, d and a.  With x_k = d*y_k:
+// gx_j = (gy_j - [j==a] * sign(y_a) * sum_k(gy_k y_k)) / d
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_max_abs_bwd_y_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ gy,
+                                                               const float* __restrict__ den,
+                                                               const int32_t* __restrict__ amax,
+                                                               float* __restrict__ gx, int B,
+                                                               int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> ry, rg;
+  ry.load(y + (size_t)row * D, D, lane, 0.0f);
+  rg.load(gy + (size_t)row * D, D, lane, 0.0f);
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) s = fmaf(rg.v[c][e], ry.v[c][e], s);
+  const float dot = pp_wave_sum(s);
+  const float d = den[row];
+  const int idx = amax[row];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float g = rg.v[c][e];
+      if ((c * 64 + lane) * V + e == idx) g -= (ry.v[c][e] < 0.0f ? -dot : dot);
+      rg.v[c][e] = g / d;
+    }
+  rg.store(gx + (size_t)row * D, D, lane);
+}
+
 // ---------------------------------------------------------------------------
 // Lion / SparseLion step for up to PP_OPT_MAX_TENSORS parameters in one launch
 // (lion_pytorch.Lion as the reference's optimizer configs name it, and high-order-layers-torch's
@@ -288,6 +323,11 @@ hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float e
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st) {
   PP_NORM_DISPATCH(pp_max_abs_bwd_kernel, x, gy, gx, B, D, eps);
+}
+
+hipError_t pp_launch_max_abs_bwd_y(const float* y, const float* gy, const float* den,
+                                   const int32_t* amax, float* gx, int B, int D, hipStream_t st) {
+  PP_NORM_DISPATCH(pp_max_abs_bwd_y_kernel, y, gy, den, amax, gx, B, D);
 }
 
 hipError_t pp_launch_lion(int count, float* const* p, const float* const* g, float* const* m,

@@ -373,6 +373,71 @@ def piecewise_poly_layer_norm(x, w, spec: LayerSpec, eps: float = 1e-5) -> torch
     return PiecewisePolyLayerNormFunction.apply(x, w, spec, eps)
 
 
+def max_abs_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> bool:
+    """True when `MaxAbsNormalizationLast(piecewise_poly(x, w))` has the fused kernel (the
+    layers the gather kernels serve) and the automatic method choice is in force."""
+    if spec.fwd_method != "auto" or spec.bwd_x_method != "auto" or x.dim() != 2 or \
+            not x.is_cuda or x.shape[0] == 0:
+        return False
+    O, I, _ = w.shape
+    return bool(_lib.load().pp_forward_max_abs_supported(
+        x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length))
+
+
+class PiecewisePolyMaxAbsFunction(torch.autograd.Function):
+    """y = MaxAbsNormalizationLast(piecewise_poly(x, w)) with the normalisation in the gather
+    kernel's epilogue.  Saves (x, w, y, den, amax); the backward is the max-abs backward from the
+    normalised row, then the layer's two backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, w: torch.Tensor, spec: LayerSpec, eps: float):
+        lib = _lib.load()
+        _require_gpu(x, "x")
+        _require_gpu(w, "w")
+        x = x.contiguous()
+        w_t = kernel_layout(w.detach())
+        B, I = x.shape
+        O = w_t.shape[2]
+        y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+        den = torch.empty(B, device=x.device, dtype=torch.float32)
+        amax = torch.empty(B, device=x.device, dtype=torch.int32)
+        with torch.cuda.device(x.device):
+            rc = lib.pp_forward_max_abs_f32(
+                _ptr(x), _ptr(w_t), _ptr(y), _ptr(den), _ptr(amax), B, I, O, spec.n, spec.segments,
+                int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale, eps,
+                _stream(x.device))
+        _lib.check(rc, "pp_forward_max_abs_f32")
+        ctx.spec = spec
+        ctx.save_for_backward(x, w, y, den, amax)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        lib = _lib.load()
+        x, w, y, den, amax = ctx.saved_tensors
+        spec = ctx.spec
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        B, O = y.shape
+        g = torch.empty_like(y)  # gradient w.r.t. the layer's (never stored) raw output
+        with torch.cuda.device(y.device):
+            rc = lib.pp_max_abs_norm_bwd_y_f32(_ptr(y), _ptr(gy), _ptr(den), _ptr(amax), _ptr(g),
+                                               B, O, _stream(y.device))
+        _lib.check(rc, "pp_max_abs_norm_bwd_y_f32")
+        w_t = kernel_layout(w.detach())
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = backward_input_raw(x, g, w_t, spec)
+        if ctx.needs_input_grad[1]:
+            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec).permute(2, 0, 1)
+        return gx, gw, None, None
+
+
+def piecewise_poly_max_abs(x, w, spec: LayerSpec, eps: float = 1e-6) -> torch.Tensor:
+    return PiecewisePolyMaxAbsFunction.apply(x, w, spec, eps)
+
+
 # ---------------------------------------------------------------------------
 # row-wise normalisations between the layers (HIP kernels in csrc/pp_norm.hip)
 # ---------------------------------------------------------------------------

@@ -118,6 +118,13 @@ class _Piecewise(nn.Module):
             return None
         return PF.piecewise_poly_layer_norm(self._prepare(x), self.w, self._spec, eps)
 
+    def forward_max_abs(self, x: Tensor, eps: float = 1e-6):
+        """`MaxAbsNormalizationLast()(self(x))` in one kernel where the layer runs on the gather
+        kernels (None otherwise)."""
+        if x.dim() != 2 or not PF.max_abs_fusable(x, self.w, self._spec):
+            return None
+        return PF.piecewise_poly_max_abs(self._prepare(x), self.w, self._spec, eps)
+
     def extra_repr(self) -> str:
         kind = "discontinuous" if self._discontinuous else "continuous"
         return (f"{kind}, n={self._n}, in_features={self.in_features}, "

@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import functional as PF
-from .layers import LazyLayerNormLastDim, high_order_fc_layers
+from .layers import LazyLayerNormLastDim, MaxAbsNormalizationLast, high_order_fc_layers
 
 
 class HighOrderMLP(nn.Module):
@@ -74,7 +74,8 @@ class HighOrderMLP(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         # same result as self.model(x); a polynomial layer directly followed by
-        # LazyLayerNormLastDim runs as one kernel where the layer has the fused epilogue
+        # LazyLayerNormLastDim (or MaxAbsNormalizationLast) runs as one kernel where the layer
+        # has the fused epilogue
         mods = list(self.model)
         if x.is_cuda and x.dim() == 2:
             # the weights of all matrix-core layers are pre-split for this step in two launches
@@ -85,6 +86,13 @@ class HighOrderMLP(nn.Module):
             if i + 1 < len(mods) and isinstance(mods[i + 1], LazyLayerNormLastDim) and \
                     hasattr(m, "forward_layer_norm"):
                 fused = m.forward_layer_norm(x, LazyLayerNormLastDim.EPS)
+                if fused is not None:
+                    x = fused
+                    i += 2
+                    continue
+            if i + 1 < len(mods) and isinstance(mods[i + 1], MaxAbsNormalizationLast) and \
+                    hasattr(m, "forward_max_abs"):
+                fused = m.forward_max_abs(x, mods[i + 1]._eps)
                 if fused is not None:
                     x = fused
                     i += 2

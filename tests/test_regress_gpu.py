@@ -278,6 +278,86 @@ def test_gather_forward_with_fused_layer_norm(case):
     assert (y1[rows].cpu().double() - yr).abs().max().item() <= 2e-5 * yr.abs().max().item()
 
 
+@pytest.mark.parametrize("case", GATHER_LN_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_gather_forward_with_fused_max_abs(case):
+    """f2: y = MaxAbs(layer(x)) from one kernel == gather forward then the max-abs kernel, bit
+    for bit; the backward from (y, den, argmax) against the unfused one (which keeps the raw
+    layer output) and the fp64 autograd of the pair."""
+    from language_interpolation_amd import _lib
+    disc, n, S, I, O, B, dist = case
+    length = 3.0 if (S == 2) else 2.0
+    lib = _lib.load()
+    assert lib.pp_forward_max_abs_supported(B, I, O, n, S, int(disc), length) == 2
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=140 + n)
+    xd, wd, gyd = x.cuda(), w.cuda(), gy.cuda()
+    spec = PF.make_spec(n, S, disc, length=length, in_features=I)
+    plain = PF.make_spec(n, S, disc, length=length, fwd_method="gather", in_features=I)
+    w1 = wd.clone().requires_grad_(True)
+    x1 = xd.clone().requires_grad_(True)
+    y1 = PF.piecewise_poly_max_abs(x1, w1, spec, 1e-6)
+    w2 = wd.clone().requires_grad_(True)
+    x2 = xd.clone().requires_grad_(True)
+    y2 = PF.MaxAbsLastFunction.apply(PF.piecewise_poly(x2, w2, plain), 1e-6)
+    assert torch.equal(y1, y2)
+    y1.backward(gyd)
+    y2.backward(gyd)
+    assert rel_err(w1.grad.cpu(), w2.grad.cpu()) <= TOL
+    if n > 1:
+        assert rel_err(x1.grad.cpu(), x2.grad.cpu()) <= TOL
+    # fp64 autograd through the oracle's layer output and the reference's normalisation formula
+    rows = slice(0, min(B, 400))
+    ref = oracle_all(x[rows], w, gy[rows], n, S, disc, length=length)
+    raw = ref["y"].double().requires_grad_(True)
+    yr = raw / (raw.abs().max(dim=-1, keepdim=True)[0] + 1e-6)
+    assert (y1[rows].cpu().double() - yr.detach()).abs().max().item() <= 2e-5
+    yr.backward(gy[rows].double())
+    g_fused = torch.empty(rows.stop, O, device="cuda")
+    # (den, amax) of the fused forward, through the C-ABI
+    yy = torch.empty(B, O, device="cuda")
+    den = torch.empty(B, device="cuda")
+    amax = torch.empty(B, device="cuda", dtype=torch.int32)
+    w_t = PF.kernel_layout(wd)
+    rc = lib.pp_forward_max_abs_f32(xd.data_ptr(), w_t.data_ptr(), yy.data_ptr(), den.data_ptr(),
+                                    amax.data_ptr(), B, I, O, n, S, int(disc), length,
+                                    spec.node_array(), spec.out_scale, 1e-6,
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and torch.equal(yy, y1.detach())
+    raw_gpu = PF.forward_raw(xd, w_t, plain)[0]
+    assert torch.equal(amax.long().cpu(), raw_gpu.abs().argmax(dim=-1).cpu())
+    assert torch.equal(den.cpu(), raw_gpu.abs().max(dim=-1)[0].cpu() + 1e-6)
+    gyc = gyd[rows].contiguous()
+    rc = lib.pp_max_abs_norm_bwd_y_f32(yy.data_ptr(), gyc.data_ptr(), den.data_ptr(),
+                                       amax.data_ptr(), g_fused.data_ptr(), rows.stop, O,
+                                       torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert rel_err(g_fused.cpu().double(), raw.grad) <= TOL
+
+
+def test_high_order_mlp_with_max_abs_between_layers_fuses_on_the_gather_layers():
+    """HighOrderMLP(normalization=MaxAbsNormalizationLast): same outputs and gradients with
+    the fused layer+maxabs kernels as with every module run on its own."""
+    import language_interpolation_amd as lia
+    torch.manual_seed(5)
+    net = lia.HighOrderMLP(layer_type="discontinuous", n=2, in_width=16, out_width=24,
+                           hidden_layers=1, hidden_width=200, in_segments=128, out_segments=40,
+                           hidden_segments=60, normalization=lia.MaxAbsNormalizationLast,
+                           device="cuda")
+    x = (torch.rand(300, 16, device="cuda") * 2 - 1)
+    gy = torch.randn(300, 24, device="cuda")
+    y1 = net(x)
+    y1.backward(gy)
+    g1 = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    y2 = net.model(x)  # nn.Sequential: one module at a time
+    y2.backward(gy)
+    g2 = [p.grad.clone() for p in net.parameters()]
+    assert torch.equal(y1, y2)
+    for a, b in zip(g1, g2):
+        assert rel_err(a.cpu(), b.cpu()) <= TOL
+
+
 # BASELINE layer shapes at the bench batch (dense-regime layers) / a quarter of it (many-segment
 # layers: the fp64 oracle's expanded basis is B*I*K doubles)
 ROWWISE_SHAPES = [
