@@ -27,6 +27,14 @@ __global__ __launch_bounds__(256) void pp_segment_ids_kernel(const float* __rest
   for (; idx < total; idx += step) seg[idx] = pp_segment(x[idx], length, half, Sf, S);
 }
 
+// inputs whose weight rows are loaded together by a wave that owns ONE row (the small-batch
+// variants): about 32 floats in flight per lane, 8 inputs at most (floats = what one input loads
+// per lane).  Waves with several rows already have a load per row in flight and enough
+// neighbours; two inputs at a time measured slower there (cfg3 hidden, 16384 rows: 128 vs 110 us).
+constexpr int gather_unroll(int floats, int rows_per_wave) {
+  return rows_per_wave > 1 || floats >= 32 ? 1 : (32 / floats > 8 ? 8 : 32 / floats);
+}
+
 // ---------------------------------------------------------------------------
 // forward
 //   grid.x: groups of 4*RW rows (4 waves per block, RW rows per wave)
@@ -69,7 +77,34 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restr
       if (write_seg && valid && row0 + r < sh.B) seg_out[(size_t)b * sh.I + i] = s;
     }
     const int cnt = min(64, sh.I - i0);
-    for (int ii = 0; ii < cnt; ++ii) {
+    // U inputs at a time, all their loads issued before the first use: one load in flight per
+    // wave (what the plain loop compiles to) ran the few waves of a small batch at the L2
+    // latency per input.  Same order of additions as the plain loop.
+    constexpr int U = gather_unroll(RW * N * V, RW);
+    int ii = 0;
+    for (; ii + U <= cnt; ii += U) {
+      PPVec<V> wv[U][RW][N];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int ko = pp_readlane_i(koff[r], ii + u);
+          const float* p = wt + (size_t)ko * sh.O + oc;
+#pragma unroll
+          for (int j = 0; j < N; ++j) wv[u][r][j].load(p + (size_t)j * sh.O);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float lj = pp_readlane_f(l[r][j], ii + u);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[r][v] = fmaf(lj, wv[u][r][j].v[v], acc[r][v]);
+          }
+    }
+    for (; ii < cnt; ++ii) {
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const int ko = pp_readlane_i(koff[r], ii);
@@ -109,14 +144,13 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restr
 // eps)); `rstd` then receives the denominator and `amax` the first index attaining the maximum,
 // which is all pp_max_abs_bwd_y_kernel (pp_norm.hip) needs besides the normalised row.
 // ---------------------------------------------------------------------------
-template <int N, int V, int CH, int NORM>
+template <int N, int V, int CH, int NORM, int RW>
 __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wt,
                                                                float* __restrict__ y,
                                                                float* __restrict__ rstd,
                                                                int32_t* __restrict__ amax,
                                                                PPShape sh, BasisTab tab, float eps) {
-  constexpr int RW = (CH * V <= 8) ? 2 : 1;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int row0 = (blockIdx.x * 4 + wave) * RW;
@@ -152,7 +186,36 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
       koff[r] = (valid ? i : 0) * sh.K + s * sh.stride;
     }
     const int cnt = min(64, sh.I - i0);
-    for (int ii = 0; ii < cnt; ++ii) {
+    constexpr int U = gather_unroll(RW * N * V * CH, RW);  // as in pp_fwd_gather_kernel
+    int ii = 0;
+    for (; ii + U <= cnt; ii += U) {
+      PPVec<V> wv[U][RW][N][CH];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int ko = pp_readlane_i(koff[r], ii + u);
+          const float* p = wt + (size_t)ko * sh.O;
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) wv[u][r][j][c].load(p + (size_t)j * sh.O + dcl[c]);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float lj = pp_readlane_f(l[r][j], ii + u);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+              for (int v = 0; v < V; ++v)
+                acc[r][c][v] = fmaf(lj, wv[u][r][j][c].v[v], acc[r][c][v]);
+          }
+    }
+    for (; ii < cnt; ++ii) {
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const int ko = pp_readlane_i(koff[r], ii);
@@ -246,7 +309,7 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
 // backward w.r.t. the input: one wave per row; lanes span `out`, one wave
 // reduction per (row, input, out-chunk).
 // ---------------------------------------------------------------------------
-template <int N, int V>
+template <int N, int V, int U>
 __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ gy,
                                                                   const float* __restrict__ wt,
@@ -284,7 +347,39 @@ __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* _
 #pragma unroll
         for (int v = 0; v < V; ++v) g.v[v] = 0.0f;
       }
-      for (int ii = 0; ii < cnt; ++ii) {
+      // U inputs at a time: their weight rows are all requested before the first dot product
+      // and the U wave reductions interleave (one input at a time ran at one L2 latency plus
+      // one dependent reduction chain per input: 78 us for 256 rows of 200 inputs)
+      int ii = 0;
+      for (; ii + U <= cnt; ii += U) {
+        PPVec<V> wv[U][N];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ko = pp_readlane_i(koff, ii + u);
+          const float* p = wt + (size_t)ko * sh.O + oc;
+#pragma unroll
+          for (int j = 0; j < N; ++j) wv[u][j].load(p + (size_t)j * sh.O);
+        }
+        float part[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          part[u] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float cj = pp_readlane_f(dl[j], ii + u);
+            float d = 0.0f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) d = fmaf(wv[u][j].v[v], g.v[v], d);
+            part[u] = fmaf(cj, d, part[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) part[u] = pp_wave_sum(part[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (lane == ii + u) res += part[u];
+      }
+      for (; ii < cnt; ++ii) {
         const int ko = pp_readlane_i(koff, ii);
         const float* p = wt + (size_t)ko * sh.O + oc;
         float part = 0.0f;
@@ -398,9 +493,11 @@ template <int N, int V>
 hipError_t fwd_dispatch_rw(const float* x, const float* wt, float* y, int32_t* seg,
                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   const int nchunk = (sh.O + 64 * V - 1) / (64 * V);
-  // enough waves to fill 256 CUs first; then amortise the per-pair prologue over RW rows
+  // one row per wave with several inputs' loads in flight (gather_unroll) until the waves fill
+  // the chip twice over; then four rows per wave (cfg3 hidden, 200 -> 200: 46 vs 81 us at 4096
+  // rows, 96 vs 85 at 8192, 109 at 16384 with four rows)
   const long waves1 = (long)sh.B * nchunk;
-  if (waves1 >= 4L * 4096) {
+  if (waves1 >= 8192) {
     constexpr int RW = 4;
     dim3 grid((sh.B + 4 * RW - 1) / (4 * RW), nchunk);
     hipLaunchKernelGGL((pp_fwd_gather_kernel<N, V, RW>), grid, dim3(256), 0, st, x, wt, y, seg, sh,
@@ -424,22 +521,29 @@ hipError_t fwd_dispatch_v(const float* x, const float* wt, float* y, int32_t* se
   }
 }
 
+template <int N, int V>
+void bwdx_launch(const float* x, const float* gy, const float* wt, float* gx, const PPShape& sh,
+                 const BasisTab& tab, hipStream_t st) {
+  dim3 grid((sh.B + 3) / 4);
+  // few rows: the unrolled loop (38 vs 77 us at 1000 rows of the n = 2, 200 -> 200, 150-segment
+  // layer); many rows: the plain one, whose waves hide each other's latency (302 vs 409 us at
+  // 16384 rows)
+  constexpr int U = gather_unroll(N * V, 1);
+  if (sh.B <= 4096)
+    hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, V, U>), grid, dim3(256), 0, st, x, gy, wt, gx,
+                       sh, tab);
+  else
+    hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, V, 1>), grid, dim3(256), 0, st, x, gy, wt, gx,
+                       sh, tab);
+}
+
 template <int N>
 hipError_t bwdx_dispatch_v(const float* x, const float* gy, const float* wt, float* gx,
                            const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  dim3 grid((sh.B + 3) / 4);
   switch (pick_vec(sh.O)) {
-    case 4:
-      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 4>), grid, dim3(256), 0, st, x, gy, wt, gx,
-                         sh, tab);
-      break;
-    case 2:
-      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 2>), grid, dim3(256), 0, st, x, gy, wt, gx,
-                         sh, tab);
-      break;
-    default:
-      hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, 1>), grid, dim3(256), 0, st, x, gy, wt, gx,
-                         sh, tab);
+    case 4: bwdx_launch<N, 4>(x, gy, wt, gx, sh, tab, st); break;
+    case 2: bwdx_launch<N, 2>(x, gy, wt, gx, sh, tab, st); break;
+    default: bwdx_launch<N, 1>(x, gy, wt, gx, sh, tab, st);
   }
   return hipGetLastError();
 }
@@ -513,10 +617,16 @@ hipError_t fwd_ln_dispatch(const float* x, const float* wt, float* y, float* rst
   if (!gather_ln_combo(sh.O, V, CH)) return hipErrorInvalidValue;
 #define PP_LN_CASE(V_, CH_)                                                                  \
   if (V == V_ && CH == CH_) {                                                                \
-    constexpr int RW = (CH_ * V_ <= 8) ? 2 : 1;                                              \
-    hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM>),                            \
-                       dim3((sh.B + 4 * RW - 1) / (4 * RW)), dim3(256), 0, st, x, wt, y, rstd, \
-                       amax, sh, tab, eps);                                                  \
+    /* two rows per wave once the waves fill the chip and the rows fit the registers; one  */ \
+    /* row and several inputs' loads in flight (gather_unroll) for a small batch           */ \
+    if (CH_ * V_ <= 8 && sh.B >= 8192)                                                       \
+      hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 2>),                     \
+                         dim3((sh.B + 7) / 8), dim3(256), 0, st, x, wt, y, rstd, amax, sh,   \
+                         tab, eps);                                                          \
+    else                                                                                     \
+      hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 1>),                     \
+                         dim3((sh.B + 3) / 4), dim3(256), 0, st, x, wt, y, rstd, amax, sh,   \
+                         tab, eps);                                                          \
     return hipGetLastError();                                                                \
   }
   PP_LN_CASE(4, 1) PP_LN_CASE(4, 2) PP_LN_CASE(4, 4)

@@ -73,6 +73,16 @@ def main():
                     continue
                 by = 4 * (B * I + B * O + W)
                 rows.append((f"fwd/{m}", t, by, 2 * B * I * O * n))
+            # layer + LayerNorm in one kernel, where the automatic choice has it (1: matrix-core,
+            # 2: gather)
+            mode = lib.pp_forward_layer_norm_supported(B, I, O, n, S, int(disc), 2.0)
+            if mode:
+                w_log = w_t.permute(2, 0, 1)
+                spec = PF.make_spec(n, S, disc)
+                with torch.no_grad():
+                    t = time_fn(lambda: PF.piecewise_poly_layer_norm(x, w_log, spec, 1e-5),
+                                args.iters)
+                rows.append((f"fwd+LN/{mode}", t, 4 * (B * I + B * O + W), 2 * B * I * O * n))
             if not first:
                 for m in ("gather", "dense", "bf16x3", "fp16x2"):
                     spec = PF.make_spec(n, S, disc, bwd_x_method=m)
