@@ -85,6 +85,16 @@ bool dense_preferred(const PPShape& sh) {
   return pp_dense_supported(sh) && sh.K <= 8 && sh.I >= 32 && sh.O >= 32;
 }
 
+// Under 256 rows (the Mamba projections at the reference's b = 16: 240 rows) the matrix-core
+// forward is a chain of k-steps in a handful of workgroups, and the gather kernel with several
+// inputs' loads in flight is faster on every projection shape (256 -> 256: 28 vs 56 us f32-MFMA,
+// 31 fp16x2; 128 -> 128: 15 vs 30; tools/small_rows.py).  Backward-input: the gather kernel only
+// for narrow inputs (64 -> 256: 12 vs 26 us), the f32-MFMA kernel otherwise.
+bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
+bool matrix_core_bwd_x(const PPShape& sh) {
+  return dense_preferred(sh) && (sh.B >= 256 || sh.I > 64);
+}
+
 }  // namespace
 
 extern "C" {
@@ -114,10 +124,11 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   if (rc != PP_OK) return rc;
   const bool dense = dense_preferred(sh);
   switch (pass) {
-    case 0: return dense ? (pp_bf3_supported(sh) && B >= 256 ? PP_FWD_FP16X2 : PP_FWD_DENSE)
-                         : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
-    case 1: return dense ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
-                         : PP_BWD_X_GATHER;
+    case 0: return matrix_core_fwd(sh) ? (pp_bf3_supported(sh) ? PP_FWD_FP16X2 : PP_FWD_DENSE)
+                                       : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
+    case 1: return matrix_core_bwd_x(sh)
+                       ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
+                       : PP_BWD_X_GATHER;
     case 2:
       if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
       if (pp_regacc_preferred(sh)) return PP_BWD_W_REGACC;
@@ -183,8 +194,8 @@ int pp_pack_weights_multi_f32(int count, const float* const* w_t, void* const* p
 }
 
 static int fwd_auto(const PPShape& sh, bool have_ws) {
-  if (!dense_preferred(sh)) return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
-  if (have_ws && pp_bf3_supported(sh) && sh.B >= 256) return PP_FWD_FP16X2;
+  if (!matrix_core_fwd(sh)) return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
+  if (have_ws && pp_bf3_supported(sh)) return PP_FWD_FP16X2;
   return PP_FWD_DENSE;
 }
 
@@ -270,7 +281,7 @@ int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* 
 }
 
 static int bwd_x_auto(const PPShape& sh, bool have_ws) {
-  if (!dense_preferred(sh)) return PP_BWD_X_GATHER;
+  if (!matrix_core_bwd_x(sh)) return PP_BWD_X_GATHER;
   if (have_ws && pp_bf3_bwd_x_supported(sh) && sh.B >= 256) return PP_BWD_X_FP16X2;
   return PP_BWD_X_DENSE;
 }
@@ -447,7 +458,7 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
     return 1;
   // layers the gather kernels serve (many segments, first layers, lengths off the matrix-core
   // path): fused there too
-  if (!dense_preferred(sh) && pp_gather_ln_supported(sh)) return 2;
+  if (!matrix_core_fwd(sh) && pp_gather_ln_supported(sh)) return 2;
   return 0;
 }
 
@@ -471,7 +482,7 @@ int pp_forward_max_abs_supported(int B, int I, int O, int n, int S, int disconti
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   // the gather kernels' layers only: the matrix-core forward has no max-abs epilogue
-  return (!dense_preferred(sh) && pp_gather_ln_supported(sh)) ? 2 : 0;
+  return (!matrix_core_fwd(sh) && pp_gather_ln_supported(sh)) ? 2 : 0;
 }
 
 static int scan_args_ok(int b, int l, int d, int n) {

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
         for (int q = 0; q < 16; ++q) acc[T / NT][T % NT][q] *= oscale;
       }
     });
+    PP_TICK(4)
     if (rstd_out) {
       // fused non-affine LayerNorm over the row (the block holds whole rows: grid.y == 1):
       // two passes (mean, then centred second moment), partial row sums per wave in LDS
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
         }
       });
     }
+    PP_TICK(5)
     static_for<NTILE>([&](auto tc) {
       constexpr int T = decltype(tc)::value;
       if constexpr (kept(T)) {

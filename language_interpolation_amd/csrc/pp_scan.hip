@@ -187,11 +187,227 @@ __global__ __launch_bounds__(64) void pp_scan_bwd_kernel(
   if (live) atomicAdd(gD + ch, gd_acc);
 }
 
+// ---------------------------------------------------------------------------
+// The same recurrences with the STATES of a channel spread over the waves of a block
+// (n <= kSplitWaves * kSS): block = 64 channels x nw waves, wave w owns states
+// [w*kSS, w*kSS + kSS).  The one-wave kernels above walk l steps x n/16 chunks one after the
+// other with every step's loads issued inside the step -- at l = 15 that is 30 dependent round
+// trips per block, 54-66 us for a forward whose arithmetic is a few microseconds (b = 16), and
+// still latency at b = 1024.  Here a wave walks the l steps once over 8 states, the next
+// step's delta/u/gy (vector) and B_t/C_t (scalar) loads are issued before the current step's
+// arithmetic, and the sums over states (y; gdelta, gu) are finished across the waves through
+// LDS once per tile of kTT steps.
+// ---------------------------------------------------------------------------
+constexpr int kSS = 8;            // states per wave
+constexpr int kSplitWaves = 8;    // up to 64 states
+constexpr int kTT = 16;           // time steps per LDS tile
+
+__global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_fwd_split_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    float* __restrict__ y, float* __restrict__ xhist, int l, int d, int n) {
+  __shared__ float ypart[kTT][kSplitWaves][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  const int b = blockIdx.y;
+  const int ch = blockIdx.x * 64 + lane;
+  const bool live = ch < d;
+  const int chc = live ? ch : d - 1;
+  const int s0 = w * kSS;
+  int sj[kSS];  // clamped state index: waves past n compute on state n-1 and are not stored
+  float a[kSS], x[kSS];
+#pragma unroll
+  for (int j = 0; j < kSS; ++j) {
+    sj[j] = min(s0 + j, n - 1);
+    a[j] = A[(size_t)chc * n + sj[j]];
+    x[j] = 0.0f;
+  }
+  const size_t row0 = (size_t)b * l;
+  float dt = delta[row0 * d + chc], uu = u[row0 * d + chc];
+  float bv[kSS], cv[kSS];
+#pragma unroll
+  for (int j = 0; j < kSS; ++j) {
+    bv[j] = Bm[row0 * n + sj[j]];
+    cv[j] = Cm[row0 * n + sj[j]];
+  }
+  for (int t0 = 0; t0 < l; t0 += kTT) {
+    const int tn = min(kTT, l - t0);
+    for (int tt = 0; tt < tn; ++tt) {
+      const size_t row = row0 + t0 + tt;
+      const size_t nxt = row0 + min(t0 + tt + 1, l - 1);  // next step's operands
+      const float dt_n = delta[nxt * d + chc], uu_n = u[nxt * d + chc];
+      float bn[kSS], cn[kSS];
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        bn[j] = Bm[nxt * n + sj[j]];
+        cn[j] = Cm[nxt * n + sj[j]];
+      }
+      const float du = dt * uu;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        x[j] = fmaf(expf(dt * a[j]), x[j], du * bv[j]);
+        if (s0 + j < n) {  // wave-uniform
+          acc = fmaf(x[j], cv[j], acc);
+          if (xhist && live) xhist[(row * n + s0 + j) * d + ch] = x[j];
+        }
+      }
+      ypart[tt][w][lane] = acc;
+      dt = dt_n;
+      uu = uu_n;
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        bv[j] = bn[j];
+        cv[j] = cn[j];
+      }
+    }
+    __syncthreads();
+    for (int tt = w; tt < tn; tt += nw) {  // wave w finishes steps w, w + nw, ...
+      float sum = 0.0f;
+      for (int q = 0; q < nw; ++q) sum += ypart[tt][q][lane];
+      const size_t row = row0 + t0 + tt;
+      if (live) y[row * d + ch] = fmaf(D[chc], u[row * d + chc], sum);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_bwd_split_kernel(
+    const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
+    const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
+    const float* __restrict__ gy, const float* __restrict__ xhist, float* __restrict__ gu,
+    float* __restrict__ gdelta, float* __restrict__ gAt, float* __restrict__ gB,
+    float* __restrict__ gC, float* __restrict__ gD, int l, int d, int n) {
+  // red: per wave, rows 0..7 = gy*x_t of the wave's 8 states (-> gC), rows 8..15 =
+  // gx*delta*u (-> gB), one value per lane; lane L then adds 16 consecutive lanes' values of
+  // row L/4 and the four lanes of a row finish with a quad sum (LDS operations of a wave
+  // execute in order: no barrier between the write and the read phase).
+  __shared__ __align__(16) float red[kSplitWaves][2 * kSS][64];
+  __shared__ float gpart[kTT][kSplitWaves][2][64];  // per wave sums over its states: gdelta, gu
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nw = blockDim.x >> 6;
+  const int b = blockIdx.y;
+  const int ch = blockIdx.x * 64 + lane;
+  const bool live = ch < d;
+  const int chc = live ? ch : d - 1;
+  const int s0 = w * kSS;
+  const int rs = lane >> 2, rq = lane & 3;  // reduce role: row rs of red, quarter rq
+  int sj[kSS];
+  float a[kSS], gx[kSS], ga[kSS], xt[kSS], xp[kSS];
+  const size_t row0 = (size_t)b * l;
+  const size_t last = row0 + l - 1;
+#pragma unroll
+  for (int j = 0; j < kSS; ++j) {
+    sj[j] = min(s0 + j, n - 1);
+    a[j] = A[(size_t)chc * n + sj[j]];
+    gx[j] = 0.0f;  // d loss / d x_t, carried backwards
+    ga[j] = 0.0f;
+    xt[j] = xhist[(last * n + sj[j]) * d + chc];
+    xp[j] = l > 1 ? xhist[((last - 1) * n + sj[j]) * d + chc] : 0.0f;
+  }
+  float dt = delta[last * d + chc], uu = u[last * d + chc];
+  float g = live ? gy[last * d + chc] : 0.0f;
+  float bv[kSS], cv[kSS];
+#pragma unroll
+  for (int j = 0; j < kSS; ++j) {
+    bv[j] = Bm[last * n + sj[j]];
+    cv[j] = Cm[last * n + sj[j]];
+  }
+  float gd_acc = 0.0f;
+  // tiles of kTT steps, last tile first; inside a tile t runs downwards
+  for (int t1 = l; t1 > 0; t1 -= kTT) {
+    const int tb = max(0, t1 - kTT);  // tile = [tb, t1)
+    for (int t = t1 - 1; t >= tb; --t) {
+      const size_t row = row0 + t;
+      const size_t prv = row0 + max(t - 1, 0);
+      const float dt_n = delta[prv * d + chc], uu_n = u[prv * d + chc];
+      const float g_n = live ? gy[prv * d + chc] : 0.0f;
+      float bn[kSS], cn[kSS], xn[kSS];
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        bn[j] = Bm[prv * n + sj[j]];
+        cn[j] = Cm[prv * n + sj[j]];
+        xn[j] = t > 1 ? xhist[((row - 2) * n + sj[j]) * d + chc] : 0.0f;
+      }
+      float gdt = 0.0f, guu = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        const float e = expf(dt * a[j]);
+        gx[j] = fmaf(g, cv[j], gx[j]);
+        const float pc = g * xt[j];            // gC[b,t,s] = sum_d gy * x_t
+        const float pb = gx[j] * dt * uu;      // gB[b,t,s] = sum_d gx * delta * u
+        const float exp_xp = e * xp[j];
+        if (s0 + j < n) {  // wave-uniform
+          gdt = fmaf(gx[j], fmaf(a[j], exp_xp, bv[j] * uu), gdt);
+          guu = fmaf(gx[j] * dt, bv[j], guu);
+        }
+        ga[j] = fmaf(gx[j] * dt, exp_xp, ga[j]);
+        gx[j] *= e;
+        red[w][j][lane] = pc;
+        red[w][kSS + j][lane] = pb;
+      }
+      {
+        const float4* rr = reinterpret_cast<const float4*>(&red[w][rs][rq * 16]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = rr[q];
+          sum += (v.x + v.y) + (v.z + v.w);
+        }
+        sum = quad_sum(sum);
+        const int st = s0 + (rs & (kSS - 1));
+        if (rq == 0 && st < n) atomicAdd((rs < kSS ? gC : gB) + row * n + st, sum);
+      }
+      gpart[t - tb][w][0][lane] = gdt;
+      gpart[t - tb][w][1][lane] = guu;
+      if (w == 0) gd_acc = fmaf(g, uu, gd_acc);
+#pragma unroll
+      for (int j = 0; j < kSS; ++j) {
+        xt[j] = xp[j];
+        xp[j] = xn[j];
+        bv[j] = bn[j];
+        cv[j] = cn[j];
+      }
+      dt = dt_n;
+      uu = uu_n;
+      g = g_n;
+    }
+    __syncthreads();
+    for (int tt = w; tt < t1 - tb; tt += nw) {  // wave w finishes steps tb + w, tb + w + nw, ...
+      float s1 = 0.0f, s2 = 0.0f;
+      for (int q = 0; q < nw; ++q) {
+        s1 += gpart[tt][q][0][lane];
+        s2 += gpart[tt][q][1][lane];
+      }
+      const size_t row = row0 + tb + tt;
+      if (live) {
+        gdelta[row * d + ch] = s1;
+        gu[row * d + ch] = fmaf(D[chc], gy[row * d + ch], s2);
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < kSS; ++j)
+      if (s0 + j < n) atomicAdd(gAt + (size_t)(s0 + j) * d + ch, ga[j]);  // [n][d]: coalesced
+    if (w == 0) atomicAdd(gD + ch, gd_acc);
+  }
+}
+
 }  // namespace
 
 hipError_t pp_launch_scan_fwd(const float* u, const float* delta, const float* A, const float* Bm,
                               const float* Cm, const float* D, float* y, float* xhist, int b, int l,
                               int d, int n, hipStream_t st) {
+  if (n <= kSplitWaves * kSS) {
+    const int nw = (n + kSS - 1) / kSS;
+    hipLaunchKernelGGL(pp_scan_fwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw), 0, st, u,
+                       delta, A, Bm, Cm, D, y, xhist, l, d, n);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(pp_scan_fwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,
                      Cm, D, y, xhist, l, d, n);
   return hipGetLastError();
@@ -206,6 +422,15 @@ hipError_t pp_launch_scan_bwd(const float* u, const float* delta, const float* A
   if (e == hipSuccess) e = hipMemsetAsync(gB, 0, (size_t)b * l * n * sizeof(float), st);
   if (e == hipSuccess) e = hipMemsetAsync(gC, 0, (size_t)b * l * n * sizeof(float), st);
   if (e != hipSuccess) return e;
+  // the state-split backward only while its blocks do not fill the chip: with thousands of
+  // blocks the one-wave kernel hides its round trips under other blocks and is faster
+  // (b = 1024, d = 128: 161 vs 207 us; b = 16: the step's two backward scans 167 -> see DESIGN 4c)
+  if (n <= kSplitWaves * kSS && (long)((d + 63) / 64) * b <= 1024) {
+    const int nw = (n + kSS - 1) / kSS;
+    hipLaunchKernelGGL(pp_scan_bwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw), 0, st, u,
+                       delta, A, Bm, Cm, D, gy, xhist, gu, gdelta, gAt, gB, gC, gD, l, d, n);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(pp_scan_bwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,
                      Cm, D, gy, xhist, gu, gdelta, gAt, gB, gC, gD, l, d, n);
   return hipGetLastError();

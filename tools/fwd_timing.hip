@@ -46,15 +46,19 @@ int main(int argc, char** argv) {
   unsigned long long t00 = ~0ull;
   for (int b = 0; b < nb; ++b) if (t[b * 8] < t00) t00 = t[b * 8];
   printf("ln=%d ", ln);
-  printf("scheme %d  block: start | prologue | main loop | exchange+store  (us)\n", scheme);
-  double sum[4] = {0};
+  printf("scheme %d  block: start | prologue | main loop | exchange+scale | LayerNorm | store  (us)\n", scheme);
+  const int order[6] = {0, 1, 2, 4, 5, 3};  // tick slots in program order
+  double sum[6] = {0};
   for (int b = 0; b < nb; ++b) {
-    double d[4];
+    double d[6];
     d[0] = (t[b * 8] - t00) * 0.01;
-    for (int j = 1; j < 4; ++j) d[j] = (double)(long long)(t[b * 8 + j] - t[b * 8 + j - 1]) * 0.01;
-    for (int j = 0; j < 4; ++j) sum[j] += d[j];
-    if (b < 3 || b % (nb / 4) == 0) printf("block %4d: %7.2f | %6.2f | %6.2f | %6.2f\n", b, d[0], d[1], d[2], d[3]);
+    for (int j = 1; j < 6; ++j)
+      d[j] = (double)(long long)(t[b * 8 + order[j]] - t[b * 8 + order[j - 1]]) * 0.01;
+    for (int j = 0; j < 6; ++j) sum[j] += d[j];
+    if (b < 3 || b % (nb / 4) == 0)
+      printf("block %4d: %7.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", b, d[0], d[1], d[2], d[3], d[4], d[5]);
   }
-  printf("mean      : %7.2f | %6.2f | %6.2f | %6.2f\n", sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb);
+  printf("mean      : %7.2f | %6.2f | %6.2f | %6.2f | %6.2f | %6.2f\n", sum[0] / nb, sum[1] / nb, sum[2] / nb,
+         sum[3] / nb, sum[4] / nb, sum[5] / nb);
   return 0;
 }
