@@ -86,14 +86,13 @@ bool dense_preferred(const PPShape& sh) {
 }
 
 // Under 256 rows (the Mamba projections at the reference's b = 16: 240 rows) the matrix-core
-// forward is a chain of k-steps in a handful of workgroups, and the gather kernel with several
-// inputs' loads in flight is faster on every projection shape (256 -> 256: 28 vs 56 us f32-MFMA,
-// 31 fp16x2; 128 -> 128: 15 vs 30; tools/small_rows.py).  Backward-input: the gather kernel only
-// for narrow inputs (64 -> 256: 12 vs 26 us), the f32-MFMA kernel otherwise.
+// kernels are a chain of k-steps in a handful of workgroups, and the gather kernels in their
+// one-row-per-block form (inputs spread over the four waves, several loads in flight) are
+// faster on every projection shape: forward 256 -> 256 10-14 us against 56 f32-MFMA / 20 fp16x2,
+// backward-input 14-24 us against 19-27 (kernel times, rocprofv3 trace of tools/layer_bench.py
+// at 240 rows; profiles/r02_p_small_rows_trace.txt).
 bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
-bool matrix_core_bwd_x(const PPShape& sh) {
-  return dense_preferred(sh) && (sh.B >= 256 || sh.I > 64);
-}
+bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
 
 }  // namespace
 

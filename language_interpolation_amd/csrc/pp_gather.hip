@@ -144,17 +144,28 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_kernel(const float* __restr
 // eps)); `rstd` then receives the denominator and `amax` the first index attaining the maximum,
 // which is all pp_max_abs_bwd_y_kernel (pp_norm.hip) needs besides the normalised row.
 // ---------------------------------------------------------------------------
-template <int N, int V, int CH, int NORM, int RW>
+// SPLIT (small batches, RW = 1): the four waves of a block share ONE row, each sums a quarter
+// of the inputs, and wave 0 adds the four partial rows in a fixed order (through LDS) before the
+// epilogue -- a wave's chain of dependent round trips is a quarter as long, which is what a few
+// hundred rows wait for.  NORM = -1: no normalisation (the plain forward at small batches runs
+// here too, so fused and unfused results stay bit-identical at every batch size).
+template <int N, int V, int CH, int NORM, int RW, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wt,
                                                                float* __restrict__ y,
                                                                float* __restrict__ rstd,
                                                                int32_t* __restrict__ amax,
                                                                PPShape sh, BasisTab tab, float eps) {
+  static_assert(!SPLIT || RW == 1, "the split variant owns one row per block");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * RW;
-  if (row0 >= sh.B) return;  // wave-uniform; no block barrier below
+  const int row0 = SPLIT ? (int)blockIdx.x : (blockIdx.x * 4 + wave) * RW;
+  if (row0 >= sh.B) return;  // wave-uniform (block-uniform when SPLIT: the barrier below is safe)
+  // inputs of this wave: a quarter of the row (multiples of 64 so the lane-parallel prologue
+  // stays whole), everything otherwise
+  const int iq = SPLIT ? ((sh.I + 255) / 256) * 64 : sh.I;
+  const int ibeg = SPLIT ? min(sh.I, wave * iq) : 0;
+  const int iend = SPLIT ? min(sh.I, ibeg + iq) : sh.I;
   int dcl[CH];
   bool ok[CH];
 #pragma unroll
@@ -171,21 +182,21 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[r][c][v] = 0.0f;
 
-  for (int i0 = 0; i0 < sh.I; i0 += 64) {
+  for (int i0 = ibeg; i0 < iend; i0 += 64) {
     const int i = i0 + lane;
     int koff[RW];
     float l[RW][N];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int b = min(row0 + r, sh.B - 1);
-      const bool valid = i < sh.I;
+      const bool valid = i < iend;
       const float xv = valid ? x[(size_t)b * sh.I + i] : 0.0f;
       const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
       const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
       pp_lagrange<N>(xi, tab, l[r]);
       koff[r] = (valid ? i : 0) * sh.K + s * sh.stride;
     }
-    const int cnt = min(64, sh.I - i0);
+    const int cnt = min(64, iend - i0);
     constexpr int U = gather_unroll(RW * N * V * CH, RW);  // as in pp_fwd_gather_kernel
     int ii = 0;
     for (; ii + U <= cnt; ii += U) {
@@ -234,9 +245,38 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
       }
     }
   }
+  if constexpr (SPLIT) {
+    __shared__ float part[3][CH * V][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) part[wave - 1][c * V + v][lane] = acc[0][c][v];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[0][c][v] += part[q][c * V + v][lane];
+  }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     if (row0 + r >= sh.B) break;  // wave-uniform
+    if constexpr (NORM == -1) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        if (ok[c]) {
+          PPVec<V> out;
+#pragma unroll
+          for (int v = 0; v < V; ++v) out.v[v] = acc[r][c][v] * sh.out_scale;
+          out.store(y + (size_t)(row0 + r) * sh.O + dcl[c]);
+        }
+      }
+      continue;
+    }
     if constexpr (NORM == 1) {
       float m = 0.0f;
 #pragma unroll
@@ -307,9 +347,11 @@ __global__ __launch_bounds__(256) void pp_fwd_gather_ln_kernel(const float* __re
 
 // ---------------------------------------------------------------------------
 // backward w.r.t. the input: one wave per row; lanes span `out`, one wave
-// reduction per (row, input, out-chunk).
+// reduction per (row, input, out-chunk).  SPLIT (small batches): one row per block, wave w
+// takes inputs 16w .. 16w+15 of every 64 -- the inputs are independent, so the chain of a wave
+// is a quarter as long and the results are the same bits.
 // ---------------------------------------------------------------------------
-template <int N, int V, int U>
+template <int N, int V, int U, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ gy,
                                                                   const float* __restrict__ wt,
@@ -317,7 +359,7 @@ __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* _
                                                                   PPShape sh, BasisTab tab) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
+  const int b = SPLIT ? (int)blockIdx.x : blockIdx.x * 4 + wave;
   if (b >= sh.B) return;
   const int nchunk = (sh.O + 64 * V - 1) / (64 * V);
 
@@ -336,7 +378,8 @@ __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* _
     const int koff = (valid ? i : 0) * sh.K + s * sh.stride;
 
     float res = 0.0f;
-    const int cnt = min(64, sh.I - i0);
+    const int ibeg = SPLIT ? wave * 16 : 0;
+    const int cnt = SPLIT ? min(ibeg + 16, min(64, sh.I - i0)) : min(64, sh.I - i0);
     for (int c = 0; c < nchunk; ++c) {
       const int o = (c * 64 + lane) * V;
       const bool o_ok = o < sh.O;
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* _
       // U inputs at a time: their weight rows are all requested before the first dot product
       // and the U wave reductions interleave (one input at a time ran at one L2 latency plus
       // one dependent reduction chain per input: 78 us for 256 rows of 200 inputs)
-      int ii = 0;
+      int ii = ibeg;
       for (; ii + U <= cnt; ii += U) {
         PPVec<V> wv[U][N];
 #pragma unroll
@@ -397,7 +440,7 @@ __global__ __launch_bounds__(256) void pp_bwd_input_gather_kernel(const float* _
         if (lane == ii) res += tot;
       }
     }
-    if (valid) gx[(size_t)b * sh.I + i] = res;
+    if (valid && (!SPLIT || (lane >> 4) == wave)) gx[(size_t)b * sh.I + i] = res;
   }
 }
 
@@ -529,7 +572,10 @@ void bwdx_launch(const float* x, const float* gy, const float* wt, float* gx, co
   // layer); many rows: the plain one, whose waves hide each other's latency (302 vs 409 us at
   // 16384 rows)
   constexpr int U = gather_unroll(N * V, 1);
-  if (sh.B <= 4096)
+  if (sh.B <= 1024)  // one row per block, its inputs spread over the four waves
+    hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, V, U, true>), dim3(sh.B), dim3(256), 0, st, x,
+                       gy, wt, gx, sh, tab);
+  else if (sh.B <= 4096)
     hipLaunchKernelGGL((pp_bwd_input_gather_kernel<N, V, U>), grid, dim3(256), 0, st, x, gy, wt, gx,
                        sh, tab);
   else
@@ -587,8 +633,17 @@ hipError_t pp_launch_segment_ids(const float* x, int32_t* seg, const PPShape& sh
   return hipGetLastError();
 }
 
+hipError_t pp_launch_fwd_gather_small(const float* x, const float* wt, float* y, const PPShape& sh,
+                                      const BasisTab& tab, hipStream_t st);
+
+// the split variant (one row per block): few rows, a row long enough to be worth four waves
+static bool gather_split_rows(const PPShape& sh) { return sh.B <= 1024 && sh.I >= 64; }
+
 hipError_t pp_launch_fwd_gather(const float* x, const float* wt, float* y, int32_t* seg,
                                 const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  // few rows of many inputs: one row per block, its inputs split over the four waves
+  if (!seg && pp_gather_ln_supported(sh) && gather_split_rows(sh))
+    return pp_launch_fwd_gather_small(x, wt, y, sh, tab, st);
 #define CALL(N) fwd_dispatch_v<N>(x, wt, y, seg, sh, tab, st)
   PP_SWITCH_N(sh.n, CALL)
 #undef CALL
@@ -615,18 +670,26 @@ hipError_t fwd_ln_dispatch(const float* x, const float* wt, float* y, float* rst
                            const PPShape& sh, const BasisTab& tab, float eps, hipStream_t st) {
   int V, CH;
   if (!gather_ln_combo(sh.O, V, CH)) return hipErrorInvalidValue;
+  const bool split = gather_split_rows(sh);
+  if (NORM == -1 && !split) return hipErrorInvalidValue;  // the plain forward has its own kernels
 #define PP_LN_CASE(V_, CH_)                                                                  \
   if (V == V_ && CH == CH_) {                                                                \
     /* two rows per wave once the waves fill the chip and the rows fit the registers; one  */ \
-    /* row and several inputs' loads in flight (gather_unroll) for a small batch           */ \
-    if (CH_ * V_ <= 8 && sh.B >= 8192)                                                       \
-      hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 2>),                     \
-                         dim3((sh.B + 7) / 8), dim3(256), 0, st, x, wt, y, rstd, amax, sh,   \
-                         tab, eps);                                                          \
-    else                                                                                     \
-      hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 1>),                     \
-                         dim3((sh.B + 3) / 4), dim3(256), 0, st, x, wt, y, rstd, amax, sh,   \
-                         tab, eps);                                                          \
+    /* row and several inputs' loads in flight (gather_unroll) for a small batch; one row  */ \
+    /* per BLOCK for the smallest                                                          */ \
+    if (split)                                                                               \
+      hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 1, true>), dim3(sh.B),   \
+                         dim3(256), 0, st, x, wt, y, rstd, amax, sh, tab, eps);              \
+    else if constexpr (NORM >= 0) {                                                          \
+      if (CH_ * V_ <= 8 && sh.B >= 8192)                                                     \
+        hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 2>),                   \
+                           dim3((sh.B + 7) / 8), dim3(256), 0, st, x, wt, y, rstd, amax, sh, \
+                           tab, eps);                                                        \
+      else                                                                                   \
+        hipLaunchKernelGGL((pp_fwd_gather_ln_kernel<N, V_, CH_, NORM, 1>),                   \
+                           dim3((sh.B + 3) / 4), dim3(256), 0, st, x, wt, y, rstd, amax, sh, \
+                           tab, eps);                                                        \
+    }                                                                                        \
     return hipGetLastError();                                                                \
   }
   PP_LN_CASE(4, 1) PP_LN_CASE(4, 2) PP_LN_CASE(4, 4)
@@ -645,6 +708,17 @@ hipError_t pp_launch_fwd_gather_ln(const float* x, const float* wt, float* y, fl
     case 2: return fwd_ln_dispatch<2, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
     case 3: return fwd_ln_dispatch<3, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
     case 4: return fwd_ln_dispatch<4, 0>(x, wt, y, rstd, nullptr, sh, tab, eps, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t pp_launch_fwd_gather_small(const float* x, const float* wt, float* y, const PPShape& sh,
+                                      const BasisTab& tab, hipStream_t st) {
+  switch (sh.n) {
+    case 1: return fwd_ln_dispatch<1, -1>(x, wt, y, nullptr, nullptr, sh, tab, 0.0f, st);
+    case 2: return fwd_ln_dispatch<2, -1>(x, wt, y, nullptr, nullptr, sh, tab, 0.0f, st);
+    case 3: return fwd_ln_dispatch<3, -1>(x, wt, y, nullptr, nullptr, sh, tab, 0.0f, st);
+    case 4: return fwd_ln_dispatch<4, -1>(x, wt, y, nullptr, nullptr, sh, tab, 0.0f, st);
     default: return hipErrorInvalidValue;
   }
 }
