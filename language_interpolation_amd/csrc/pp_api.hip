@@ -91,7 +91,9 @@ bool dense_preferred(const PPShape& sh) {
 // faster on every projection shape: forward 256 -> 256 10-14 us against 56 f32-MFMA / 20 fp16x2,
 // backward-input 14-24 us against 19-27 (kernel times, rocprofv3 trace of tools/layer_bench.py
 // at 240 rows; profiles/r02_p_small_rows_trace.txt).
-bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
+// The forward stays on the gather kernel a little longer (cfg2 hidden, 250 -> 250 at 256 rows:
+// 14 us against 20 for the fp16x2 kernel's 8 workgroups; level at ~400 rows, 25 vs 21 at 512).
+bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 384; }
 bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
 
 }  // namespace
@@ -452,8 +454,7 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
                                     float length) {
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
-  if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && dense_preferred(sh) &&
-      sh.B >= 256)
+  if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && matrix_core_fwd(sh))
     return 1;
   // layers the gather kernels serve (many segments, first layers, lengths off the matrix-core
   // path): fused there too

@@ -97,11 +97,18 @@ def _packed_bytes(w_t, spec: LayerSpec, B: int) -> int:
     lib = _lib.load()
     I, K, O = w_t.shape
     args = (B, I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length)
-    if lib.pp_auto_method(0, *args) != _lib.FWD_FP16X2 or \
-            lib.pp_auto_method(1, *args) != _lib.BWD_X_FP16X2:
+    # the backward-input decides: one buffer holds both layouts, and a batch just above the
+    # matrix-core threshold runs the gather forward with the fp16x2 backward-input
+    if lib.pp_auto_method(1, *args) != _lib.BWD_X_FP16X2:
         return 0
     return lib.pp_packed_weights_bytes(I, O, spec.n, spec.segments, int(spec.discontinuous),
                                        spec.length)
+
+
+def _fwd_takes_packed(w_t, spec: LayerSpec, B: int) -> bool:
+    I, K, O = w_t.shape
+    return _lib.load().pp_auto_method(0, B, I, O, spec.n, spec.segments, int(spec.discontinuous),
+                                      spec.length) == _lib.FWD_FP16X2
 
 
 # buffers written by prepack_layers for the step in flight: (storage pointer, version) -> bytes
@@ -270,7 +277,9 @@ class PiecewisePolyFunction(torch.autograd.Function):
         x = x.contiguous()
         w_t = kernel_layout(w.detach())
         packed = pack_weights(w_t, spec, x.shape[0], version=w._version)
-        y, _ = forward_raw(x, w_t, spec, packed=packed)
+        fwd_packed = packed if packed is not None and _fwd_takes_packed(w_t, spec, x.shape[0]) \
+            else None
+        y, _ = forward_raw(x, w_t, spec, packed=fwd_packed)
         ctx.spec = spec
         # the pre-split weights serve this step's backward-input too (w cannot change in
         # between: autograd checks the saved tensor's version)
@@ -328,16 +337,17 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         O = w_t.shape[2]
         mode = lib.pp_forward_layer_norm_supported(B, I, O, spec.n, spec.segments,
                                                    int(spec.discontinuous), spec.length)
-        packed = pack_weights(w_t, spec, B, version=w._version) if mode == 1 else None
+        packed = pack_weights(w_t, spec, B, version=w._version)  # (the backward-input's too)
         if mode == 0 or (mode == 1 and packed is None):
             raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
+        fwd_packed = packed if mode == 1 else None
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)
         rstd = torch.empty(B, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             # mode 2: no packed weights -> the gather kernel with whole rows per wave
             rc = lib.pp_forward_layer_norm_f32(
-                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(packed),
-                packed.numel() if packed is not None else 0, B, I, O,
+                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(fwd_packed),
+                fwd_packed.numel() if fwd_packed is not None else 0, B, I, O,
                 spec.n, spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
                 spec.out_scale, eps, _stream(x.device))
         _lib.check(rc, "pp_forward_layer_norm_f32")

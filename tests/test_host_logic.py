@@ -69,8 +69,14 @@ def test_auto_method_selection():
                                       null, 1.0, _lib.BWD_W_REGACC, null) == -4  # no workspace
     # few segments, wide layer -> expanded basis on the matrix cores (cfg2 hidden, cfg1 hidden)
     for p, want in ((0, _lib.FWD_FP16X2), (1, _lib.BWD_X_FP16X2), (2, _lib.BWD_W_DENSE)):
-        assert lib.pp_auto_method(p, 256, 250, 250, 3, 2, 0, 2.0) == want
+        assert lib.pp_auto_method(p, 512, 250, 250, 3, 2, 0, 2.0) == want
         assert lib.pp_auto_method(p, 1000, 200, 200, 2, 2, 0, 2.0) == want
+    # small batches of the same layers: gather forward under 384 rows, everything under 256
+    assert lib.pp_auto_method(0, 256, 250, 250, 3, 2, 0, 2.0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(1, 256, 250, 250, 3, 2, 0, 2.0) == _lib.BWD_X_FP16X2
+    assert lib.pp_auto_method(0, 240, 256, 256, 3, 2, 0, 2.0) == _lib.FWD_GATHER
+    assert lib.pp_auto_method(1, 240, 256, 256, 3, 2, 0, 2.0) == _lib.BWD_X_GATHER
+    assert lib.pp_auto_method(2, 240, 256, 256, 3, 2, 0, 2.0) == _lib.BWD_W_DENSE
     # K = 9 (n=5, S=2) is beyond the dense kernels -> gather
     assert lib.pp_auto_method(0, 35, 64, 64, 5, 2, 0, 2.0) == _lib.FWD_GATHER
     # a length that is not a power of two (the reference accepts any input_scale,
@@ -84,13 +90,14 @@ def test_auto_method_selection():
     assert lib.pp_forward_layer_norm_supported(256, 16, 1000, 2, 128, 1, 2.0) == 2
     assert lib.pp_forward_layer_norm_supported(256, 16, 1030, 2, 128, 1, 2.0) == 0  # O > 1024
     assert lib.pp_forward_layer_norm_supported(256, 16, 250, 5, 30, 1, 2.0) == 0    # n > 4
-    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 1
+    assert lib.pp_forward_layer_norm_supported(512, 250, 250, 3, 2, 0, 4.0) == 1
+    assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 2
     # fp16x2 layers with K >= 7 keep the fused LayerNorm up to 256 outs
-    assert lib.pp_forward_layer_norm_supported(256, 64, 256, 4, 2, 0, 2.0) == 1
+    assert lib.pp_forward_layer_norm_supported(512, 64, 256, 4, 2, 0, 2.0) == 1
     # the max-abs epilogue exists on the gather kernels only
     assert lib.pp_forward_max_abs_supported(1000, 200, 200, 1, 150, 1, 2.0) == 2
     assert lib.pp_forward_max_abs_supported(256, 16, 1000, 2, 128, 1, 2.0) == 2
-    assert lib.pp_forward_max_abs_supported(256, 250, 250, 3, 2, 0, 2.0) == 0   # matrix-core layer
+    assert lib.pp_forward_max_abs_supported(512, 250, 250, 3, 2, 0, 2.0) == 0   # matrix-core layer
     assert lib.pp_forward_max_abs_supported(256, 16, 1030, 2, 128, 1, 2.0) == 0  # O > 1024
 
 

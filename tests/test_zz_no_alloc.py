@@ -42,7 +42,7 @@ def test_noalloc_forward_matches_workspace_forward_twice():
     lib = _lib.load()
     torch.cuda.set_device(0)
     # first call: cfg2 hidden layer at a large batch; second: a smaller layer and batch
-    for (B, I, O, n, S, disc) in ((4096 + 5, 250, 250, 3, 2, False), (300, 64, 96, 2, 2, True)):
+    for (B, I, O, n, S, disc) in ((4096 + 5, 250, 250, 3, 2, False), (500, 64, 96, 2, 2, True)):
         x, w, _ = make_inputs(B, I, O, n, S, disc, "normal", seed=60 + B % 7)
         xd = x.cuda()
         w_t = w.cuda().permute(1, 2, 0).contiguous()
