@@ -200,13 +200,13 @@ __global__ __launch_bounds__(64) void pp_scan_bwd_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kSS = 8;            // states per wave
 constexpr int kSplitWaves = 8;    // up to 64 states
-constexpr int kTT = 16;           // time steps per LDS tile
+constexpr int kTT = 8;            // time steps per LDS tile
 
 __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_fwd_split_kernel(
     const float* __restrict__ u, const float* __restrict__ delta, const float* __restrict__ A,
     const float* __restrict__ Bm, const float* __restrict__ Cm, const float* __restrict__ D,
     float* __restrict__ y, float* __restrict__ xhist, int l, int d, int n) {
-  __shared__ float ypart[kTT][kSplitWaves][64];
+  extern __shared__ float ypart[];  // [kTT][nw][64]
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_fwd_split_kernel(
           if (xhist && live) xhist[(row * n + s0 + j) * d + ch] = x[j];
         }
       }
-      ypart[tt][w][lane] = acc;
+      ypart[(tt * nw + w) * 64 + lane] = acc;
       dt = dt_n;
       uu = uu_n;
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_fwd_split_kernel(
     __syncthreads();
     for (int tt = w; tt < tn; tt += nw) {  // wave w finishes steps w, w + nw, ...
       float sum = 0.0f;
-      for (int q = 0; q < nw; ++q) sum += ypart[tt][q][lane];
+      for (int q = 0; q < nw; ++q) sum += ypart[(tt * nw + q) * 64 + lane];
       const size_t row = row0 + t0 + tt;
       if (live) y[row * d + ch] = fmaf(D[chc], u[row * d + chc], sum);
     }
@@ -283,11 +283,12 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_bwd_split_kernel(
   // gx*delta*u (-> gB), one value per lane; lane L then adds 16 consecutive lanes' values of
   // row L/4 and the four lanes of a row finish with a quad sum (LDS operations of a wave
   // execute in order: no barrier between the write and the read phase).
-  __shared__ __align__(16) float red[kSplitWaves][2 * kSS][64];
-  __shared__ float gpart[kTT][kSplitWaves][2][64];  // per wave sums over its states: gdelta, gu
+  extern __shared__ __align__(16) float scan_lds[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
+  float* red = scan_lds + w * (2 * kSS * 64);         // this wave's [2*kSS][64]
+  float* gpart = scan_lds + nw * (2 * kSS * 64);      // [kTT][nw][2][64]: gdelta, gu per wave
   const int b = blockIdx.y;
   const int ch = blockIdx.x * 64 + lane;
   const bool live = ch < d;
@@ -345,11 +346,11 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_bwd_split_kernel(
         }
         ga[j] = fmaf(gx[j] * dt, exp_xp, ga[j]);
         gx[j] *= e;
-        red[w][j][lane] = pc;
-        red[w][kSS + j][lane] = pb;
+        red[j * 64 + lane] = pc;
+        red[(kSS + j) * 64 + lane] = pb;
       }
       {
-        const float4* rr = reinterpret_cast<const float4*>(&red[w][rs][rq * 16]);
+        const float4* rr = reinterpret_cast<const float4*>(&red[rs * 64 + rq * 16]);
         float sum = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_bwd_split_kernel(
         const int st = s0 + (rs & (kSS - 1));
         if (rq == 0 && st < n) atomicAdd((rs < kSS ? gC : gB) + row * n + st, sum);
       }
-      gpart[t - tb][w][0][lane] = gdt;
-      gpart[t - tb][w][1][lane] = guu;
+      gpart[(((t - tb) * nw + w) * 2 + 0) * 64 + lane] = gdt;
+      gpart[(((t - tb) * nw + w) * 2 + 1) * 64 + lane] = guu;
       if (w == 0) gd_acc = fmaf(g, uu, gd_acc);
 #pragma unroll
       for (int j = 0; j < kSS; ++j) {
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(64 * kSplitWaves) void pp_scan_bwd_split_kernel(
     for (int tt = w; tt < t1 - tb; tt += nw) {  // wave w finishes steps tb + w, tb + w + nw, ...
       float s1 = 0.0f, s2 = 0.0f;
       for (int q = 0; q < nw; ++q) {
-        s1 += gpart[tt][q][0][lane];
-        s2 += gpart[tt][q][1][lane];
+        s1 += gpart[((tt * nw + q) * 2 + 0) * 64 + lane];
+        s2 += gpart[((tt * nw + q) * 2 + 1) * 64 + lane];
       }
       const size_t row = row0 + tb + tt;
       if (live) {
@@ -404,8 +405,9 @@ hipError_t pp_launch_scan_fwd(const float* u, const float* delta, const float* A
                               int d, int n, hipStream_t st) {
   if (n <= kSplitWaves * kSS) {
     const int nw = (n + kSS - 1) / kSS;
-    hipLaunchKernelGGL(pp_scan_fwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw), 0, st, u,
-                       delta, A, Bm, Cm, D, y, xhist, l, d, n);
+    hipLaunchKernelGGL(pp_scan_fwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw),
+                       (size_t)kTT * nw * 64 * sizeof(float), st, u, delta, A, Bm, Cm, D, y, xhist,
+                       l, d, n);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(pp_scan_fwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,
@@ -422,13 +424,13 @@ hipError_t pp_launch_scan_bwd(const float* u, const float* delta, const float* A
   if (e == hipSuccess) e = hipMemsetAsync(gB, 0, (size_t)b * l * n * sizeof(float), st);
   if (e == hipSuccess) e = hipMemsetAsync(gC, 0, (size_t)b * l * n * sizeof(float), st);
   if (e != hipSuccess) return e;
-  // the state-split backward only while its blocks do not fill the chip: with thousands of
-  // blocks the one-wave kernel hides its round trips under other blocks and is faster
-  // (b = 1024, d = 128: 161 vs 207 us; b = 16: the step's two backward scans 167 -> see DESIGN 4c)
-  if (n <= kSplitWaves * kSS && (long)((d + 63) / 64) * b <= 1024) {
+  // (with its LDS sized by the waves actually launched the state-split backward wins at every
+  // batch: b = 1024, d = 128: ~100 vs 150 us -- with 96 KB of static LDS it had lost, 207 us)
+  if (n <= kSplitWaves * kSS) {
     const int nw = (n + kSS - 1) / kSS;
-    hipLaunchKernelGGL(pp_scan_bwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw), 0, st, u,
-                       delta, A, Bm, Cm, D, gy, xhist, gu, gdelta, gAt, gB, gC, gD, l, d, n);
+    hipLaunchKernelGGL(pp_scan_bwd_split_kernel, dim3((d + 63) / 64, b), dim3(64 * nw),
+                       (size_t)nw * (2 * kSS + 2 * kTT) * 64 * sizeof(float), st, u, delta, A, Bm,
+                       Cm, D, gy, xhist, gu, gdelta, gAt, gB, gC, gD, l, d, n);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(pp_scan_bwd_kernel, dim3((d + 63) / 64, b), dim3(64), 0, st, u, delta, A, Bm,

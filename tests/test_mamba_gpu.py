@@ -27,7 +27,10 @@ def scan_inputs(b, l, d, n, seed):
 
 
 # (b, l, d, n): cfg5 (d_inner 128, d_state 32, l 15), ragged channel / state counts, one step
-SCAN_CASES = [(16, 15, 128, 32), (3, 7, 70, 16), (2, 5, 130, 19), (1, 1, 1, 1), (5, 33, 64, 40)]
+# state-split kernels up to n = 64 (tiles of 8 time steps: l = 16, 17, 33 cross tile edges),
+# one-wave kernels above
+SCAN_CASES = [(16, 15, 128, 32), (3, 7, 70, 16), (2, 5, 130, 19), (1, 1, 1, 1), (5, 33, 64, 40),
+              (4, 16, 64, 32), (2, 17, 64, 8), (3, 12, 96, 33), (2, 9, 64, 70)]
 
 
 @pytest.mark.parametrize("case", SCAN_CASES, ids=lambda c: "-".join(map(str, c)))
