@@ -87,6 +87,10 @@ enum {
                           x 64 outs, keeps one register per weight row and adds the batch rows in
                           their natural order through the VGPR index mode; no sort, no zero fill, no
                           atomics, bitwise reproducible; needs a workspace */
+  PP_BWD_W_DIRECT = 7, /* small batches (B <= 1024, n <= 4) of many-segment layers: the wave that owns a
+                          weight row finds the batch rows that land on it (segment ids of the input
+                          column in LDS, ballots in row order) and stores the finished row once; no
+                          zero fill, no atomics, no workspace, bitwise reproducible */
   PP_BWD_X_GATHER = 1,
   PP_BWD_X_DENSE = 2,
   PP_BWD_X_FP16X2 = 4, /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor and gy per

@@ -134,6 +134,10 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
       if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
       if (pp_regacc_preferred(sh)) return PP_BWD_W_REGACC;
       if (pp_regacc_supported(sh)) return PP_BWD_W_ATOMIC;  // too small for anything but atomics
+      // more weight rows per input than the register accumulators hold, at the reference's
+      // batch sizes: the row-owner kernel (16 -> 1000, K = 256: 17 us against 42-45 at 256 rows,
+      // level with the sort at ~700; profiles/r02_q_small_batch_bwd_w.txt)
+      if (sh.B <= 512 && pp_direct_supported(sh)) return PP_BWD_W_DIRECT;
       return pp_sort_supported(sh) ? PP_BWD_W_SORT : PP_BWD_W_ATOMIC;
     default: return PP_ERR_METHOD;
   }
@@ -383,6 +387,9 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
       if (!workspace || workspace_bytes < need) return PP_ERR_WORKSPACE;
       return hip_rc(pp_launch_bwd_weight_sort(x, gy, gw_t, workspace, sh, tab, st));
     }
+    case PP_BWD_W_DIRECT:
+      if (!pp_direct_supported(sh)) return PP_ERR_METHOD;
+      return hip_rc(pp_launch_bwd_weight_direct(x, gy, gw_t, sh, tab, st));
     case PP_BWD_W_REGACC: {
       if (!pp_regacc_supported(sh)) return PP_ERR_METHOD;
       const size_t need = pp_regacc_workspace_bytes(sh);

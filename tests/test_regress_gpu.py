@@ -8,6 +8,7 @@ Launching every instantiation at that occupancy several times and demanding iden
 the sharpest detector for that class of fault; a row-wise comparison against the plain-fp32
 gather kernels catches a fault that became repeatable.
 """
+import ctypes
 import dataclasses
 
 import pytest
@@ -230,6 +231,57 @@ def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
                                               (I, K, O), spec)
     want_gw = ref["gw"].permute(1, 2, 0) * scale   # [O, I, K] -> kernel layout [I, K, O]
     assert rel_err(gw_tail.cpu(), want_gw) <= 4 * TOL
+
+
+# (disc, n, S, I, O, B, dist, out_scale): the small-batch weight gradient (PP_BWD_W_DIRECT)
+DIRECT_CASES = [
+    (True, 2, 128, 16, 1000, 256, "char", 1.0),         # cfg4 input layer at the reference's batch
+    (True, 2, 128, 16, 1000, 1024, "char", 1.0),        # ... at the largest batch the kernel takes
+    (False, 2, 128, 16, 250, 256, "char", 1.0),         # cfg2 input: continuous, shared nodes, V = 2
+    (True, 1, 150, 200, 200, 1000, "normal", 1.0),      # cfg3 hidden at the reference's batch
+    (False, 3, 50, 37, 70, 777, "edges", 0.5),          # n = 3 continuous, boundary values
+    (False, 4, 9, 5, 33, 65, "normal", 1.0),            # n = 4 continuous, odd O (V = 1), 65 rows
+    (True, 3, 11, 3, 130, 63, "uniform", 2.0),          # K = 33: two row groups, last one ragged
+    (True, 1, 7, 2, 4, 1, "normal", 1.0),               # a single row
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_direct_weight_gradient_matches_oracle_and_is_reproducible(case):
+    from language_interpolation_amd import _lib
+    disc, n, S, I, O, B, dist, scale = case
+    K = n * S if disc else (n - 1) * S + 1
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=170 + n)
+    xd, gyd = x.cuda(), gy.cuda()
+    spec = dataclasses.replace(PF.make_spec(n, S, disc, bwd_w_method="direct", in_features=I),
+                               out_scale=scale)
+    # every element is written: start from a poisoned buffer through the C-ABI
+    lib = _lib.load()
+    gw = torch.full((I, K, O), float("nan"), device="cuda")
+    rc = lib.pp_backward_weight_f32(xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), None, 0, B, I, O,
+                                    n, S, int(disc), 2.0, spec.node_array(), scale,
+                                    _lib.BWD_W_DIRECT, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.isfinite(gw).all()
+    for _ in range(2):  # fixed summation order: the same bits every time
+        assert torch.equal(PF.backward_weight_raw(xd, gyd, (I, K, O), spec), gw)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    want_gw = ref["gw"].permute(1, 2, 0) * scale   # [O, I, K] -> kernel layout [I, K, O]
+    assert rel_err(gw.cpu(), want_gw) <= TOL
+    # rows the batch never touches are exactly zero
+    touched = want_gw.abs().sum(dim=2) > 0
+    assert float(gw.cpu()[~touched].abs().max()) == 0.0 if (~touched).any() else True
+
+
+def test_direct_weight_gradient_refuses_large_batches():
+    from language_interpolation_amd import _lib
+    lib = _lib.load()
+    fake = ctypes.c_void_p(256)
+    assert lib.pp_backward_weight_f32(fake, fake, fake, None, 0, 1025, 16, 64, 2, 8, 1, 2.0, None,
+                                      1.0, _lib.BWD_W_DIRECT, None) == -5
+    assert lib.pp_backward_weight_f32(fake, fake, fake, None, 0, 256, 16, 64, 5, 8, 1, 2.0, None,
+                                      1.0, _lib.BWD_W_DIRECT, None) == -5
 
 
 # (disc, n, S, I, O, B, dist): LayerNorm fused into the gather forward -- every (vector width,

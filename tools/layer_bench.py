@@ -92,7 +92,7 @@ def main():
                         continue
                     by = 4 * (2 * B * I + B * O + W)
                     rows.append((f"bwd_x/{m}", t, by, 2 * B * I * O * n))
-            for m in ("atomic", "sort", "regacc", "dense", "bf16x3", "fp16x2"):
+            for m in ("atomic", "sort", "regacc", "direct", "dense", "bf16x3", "fp16x2"):
                 spec = PF.make_spec(n, S, disc, bwd_w_method=m)
                 try:
                     t = time_fn(lambda: PF.backward_weight_raw(x, gy, tuple(w_t.shape), spec),
