@@ -222,18 +222,23 @@ class _TrainModule(torch.nn.Module):
         return self.loss(y_hat, y), (torch.argmax(y_hat, dim=1) == y).float().mean()
 
 
-def train_chars_per_s(net, dev, B, steps, world, reducer, graph):
+def train_chars_per_s(net, dev, B, steps, world, reducer, graph, optimizer="sparse_lion"):
     """The other half of BASELINE's metric: optimizer steps of the same network on character
-    windows gathered on the device (cross entropy, Adam).  One process: the step is replayed
-    from a HIP graph (train.GraphedTrainStep); several: eager launches with the RCCL
-    all-reduce of the gradients overlapping the backward."""
-    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, synthetic_text
+    windows gathered on the device: cross entropy and the reference's default optimizer
+    (config/high_order_interpolation.yaml:70 `optimizer: sparse_lion`, lr 1e-5; one fused
+    kernel per step, train.Lion) or Adam.  One process: the step is replayed from a HIP graph
+    (train.GraphedTrainStep); several: eager launches with the RCCL all-reduce of the
+    gradients overlapping the backward."""
+    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, Lion, synthetic_text
 
     data = CharWindows(synthetic_text(1 << 20, seed=7), 16, device=dev)
     gen = torch.Generator(device=dev).manual_seed(11)
     module = _TrainModule(net)
     graph = graph and reducer is None
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=graph)
+    if optimizer == "adam":
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=graph)
+    else:
+        opt = Lion(net.parameters(), lr=1e-5, weight_decay=0.0, sparse=optimizer == "sparse_lion")
     graphed = GraphedTrainStep(module, opt, data.sample(B, gen)) if graph else None
 
     def one():
@@ -353,6 +358,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-layers", action="store_true", help="skip the roofline_hbm object")
     ap.add_argument("--cpu-rows", type=int, default=4096)
+    ap.add_argument("--train-optimizer", choices=("sparse_lion", "lion", "adam"),
+                    default="sparse_lion",
+                    help="optimizer of the train chars/s figure (the reference's default: sparse_lion)")
     ap.add_argument("--train-steps", type=int, default=20,
                     help="optimizer steps for the extra train chars/s figure (0 = skip)")
     args = ap.parse_args()
@@ -481,7 +489,8 @@ def main():
     if args.train_steps > 0:
         if reducer is None and world > 1:
             reducer = GradAllReducer(params)
-        train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer, not args.no_graph)
+        train_cps = train_chars_per_s(net, dev, B, args.train_steps, world, reducer, not args.no_graph,
+                                      args.train_optimizer)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -513,7 +522,9 @@ def main():
         if eager_dt is not None:
             out["eager_ms_per_step"] = round(eager_dt / args.steps * 1e3, 4)
         if train_cps is not None:
-            out["train_chars_per_s"] = round(train_cps, 1)  # cross entropy + Adam (graph replay at N=1)
+            # cross entropy + optimizer step (graph replay at N=1)
+            out["train_chars_per_s"] = round(train_cps, 1)
+            out["train_optimizer"] = args.train_optimizer
         hb = step_bytes(B)
         out["hbm_roofline"] = {"algorithmic_bytes_per_step": hb,
                                "achieved_GBs": round(hb / (dt / args.steps) * 1e-9, 1),
