@@ -217,9 +217,8 @@ class _TrainModule(torch.nn.Module):
         self.loss = torch.nn.CrossEntropyLoss()
 
     def eval_step(self, batch):
-        y_hat = self.model(batch[0])
-        y = batch[1].flatten()
-        return self.loss(y_hat, y), (torch.argmax(y_hat, dim=1) == y).float().mean()
+        from language_interpolation_amd import functional as PF
+        return PF.cross_entropy_accuracy(self.model(batch[0]), batch[1].flatten())
 
 
 def train_chars_per_s(net, dev, B, steps, world, reducer, graph, optimizer="sparse_lion"):

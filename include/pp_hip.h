@@ -259,6 +259,18 @@ int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* de
 int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
                               const int32_t* amax, float* gx, int B, int D, void* stream);
 
+/* Cross entropy of logits[B][C] (C <= 1024) against int64 class indices with the arg-max accuracy,
+ * as ASCIIPredictionNet.eval_step computes them (networks.py:121-132: CrossEntropyLoss, mean
+ * reduction; accuracy = mean(argmax == target)): loss_acc[0] = mean loss, loss_acc[1] = accuracy.
+ * Targets must lie in [0, C).  workspace: pp_cross_entropy_workspace_bytes() of device scratch.
+ * The backward recomputes the softmax: glogits = (softmax - onehot) * gout[0] / B, gout a device
+ * scalar (the gradient of the mean loss).  Bitwise reproducible. */
+size_t pp_cross_entropy_workspace_bytes(void);
+int pp_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* loss_acc,
+                             void* workspace, size_t workspace_bytes, int B, int C, void* stream);
+int pp_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout,
+                             float* glogits, int B, int C, void* stream);
+
 /* Selective scan of the reference's Mamba block (state_space_network.py:372-420: the Python
  * loop over the sequence in MambaBlock.selective_scan):
  *   x_t = exp(delta_t * A) * x_{t-1} + delta_t * B_t * u_t ;  y_t = <C_t, x_t> + D * u_t

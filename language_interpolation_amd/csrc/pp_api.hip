@@ -565,6 +565,29 @@ int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
   return hip_rc(pp_launch_max_abs_bwd_y(y, gy, den, amax, gx, B, D, (hipStream_t)stream));
 }
 
+size_t pp_cross_entropy_workspace_bytes(void) { return pp_ce_workspace_bytes(); }
+
+int pp_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* loss_acc,
+                             void* workspace, size_t workspace_bytes, int B, int C, void* stream) {
+  if (!logits || !target || !loss_acc) return PP_ERR_NULL;
+  if (!aligned16(logits)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, C);
+  if (rc != PP_OK) return rc;
+  if (!workspace || workspace_bytes < pp_ce_workspace_bytes()) return PP_ERR_WORKSPACE;
+  return hip_rc(pp_launch_ce_fwd(logits, reinterpret_cast<const long*>(target), loss_acc, workspace,
+                                 B, C, (hipStream_t)stream));
+}
+
+int pp_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* gout,
+                             float* glogits, int B, int C, void* stream) {
+  if (!logits || !target || !gout || !glogits) return PP_ERR_NULL;
+  if (!aligned16(logits) || !aligned16(glogits)) return PP_ERR_ALIGN;
+  int rc = norm_args_ok(B, C);
+  if (rc != PP_OK) return rc;
+  return hip_rc(pp_launch_ce_bwd(logits, reinterpret_cast<const long*>(target), gout, glogits, B, C,
+                                 (hipStream_t)stream));
+}
+
 static int mamba_dims_ok(long rows, int d) {
   if (rows < 1 || d < 1) return PP_ERR_SHAPE;
   if (rows * d >= (1L << 31)) return PP_ERR_RANGE;

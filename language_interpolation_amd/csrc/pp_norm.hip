@@ -222,6 +222,124 @@ __global__ __launch_bounds__(256) void pp_max_abs_bwd_y_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------
+// Cross entropy over the last dim with the accuracy of the arg-max, for the training harness
+// (ASCIIPredictionNet.eval_step, /root/reference/language_interpolation/networks.py:121-132:
+// `loss = CrossEntropyLoss()(y_hat, y)`, `accuracy = (argmax(y_hat) == y).mean()`): one pass over
+// the logits instead of log-softmax, NLL (a single-block reduction in torch: 27 us at 16384
+// rows), arg-max, compare and two means.  A wave holds a row; the block's sums of loss and hits
+// go to part[block], a second single-block kernel adds them in a fixed order -> the same bits
+// every time.  The backward recomputes the softmax from the logits:
+//   glogits = (softmax - onehot) * gout / B.
+// ---------------------------------------------------------------------------
+constexpr int kCeBlocks = 512;
+
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_ce_fwd_kernel(const float* __restrict__ logits,
+                                                        const long* __restrict__ target,
+                                                        float2* __restrict__ part, int B, int D) {
+  __shared__ float2 wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float loss_acc = 0.0f, hit_acc = 0.0f;
+  for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+    RowRegs<V, CH> r;
+    r.load(logits + (size_t)row * D, D, lane, -INFINITY);
+    const int t = (int)target[row];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < V; ++e) m = fmaxf(m, r.v[c][e]);
+    m = wave_max(m);
+    float s = 0.0f, xt = 0.0f;
+    int idx = 0x7fffffff;  // first index attaining the maximum
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const int d = (c * 64 + lane) * V + e;
+        if (d < D) {
+          s += expf(r.v[c][e] - m);
+          if (d == t) xt = r.v[c][e];
+          if (r.v[c][e] == m) idx = min(idx, d);
+        }
+      }
+    s = pp_wave_sum(s);
+    xt = pp_wave_sum(xt);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) idx = min(idx, __shfl_xor(idx, off, 64));
+    loss_acc += logf(s) + m - xt;
+    hit_acc += idx == t ? 1.0f : 0.0f;
+  }
+  if (lane == 0) wsum[wave] = make_float2(loss_acc, hit_acc);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[blockIdx.x] = make_float2((wsum[0].x + wsum[1].x) + (wsum[2].x + wsum[3].x),
+                                   (wsum[0].y + wsum[1].y) + (wsum[2].y + wsum[3].y));
+}
+
+__global__ __launch_bounds__(256) void pp_ce_finish_kernel(const float2* __restrict__ part,
+                                                           int nblk, float* __restrict__ out,
+                                                           float inv_rows) {
+  __shared__ float2 sm[256];
+  float2 a = make_float2(0.0f, 0.0f);
+  for (int i = threadIdx.x; i < nblk; i += 256) {
+    a.x += part[i].x;
+    a.y += part[i].y;
+  }
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      sm[threadIdx.x].x += sm[threadIdx.x + off].x;
+      sm[threadIdx.x].y += sm[threadIdx.x + off].y;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sm[0].x * inv_rows;  // mean loss
+    out[1] = sm[0].y * inv_rows;  // accuracy
+  }
+}
+
+template <int V, int CH>
+__global__ __launch_bounds__(256) void pp_ce_bwd_kernel(const float* __restrict__ logits,
+                                                        const long* __restrict__ target,
+                                                        const float* __restrict__ gout,
+                                                        float* __restrict__ glogits, int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  RowRegs<V, CH> r;
+  r.load(logits + (size_t)row * D, D, lane, -INFINITY);
+  const int t = (int)target[row];
+  const float scale = gout[0] / (float)B;
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) m = fmaxf(m, r.v[c][e]);
+  m = wave_max(m);
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      r.v[c][e] = expf(r.v[c][e] - m);  // (padding: exp(-inf) = 0)
+      s += r.v[c][e];
+    }
+  s = pp_wave_sum(s);
+  const float inv = 1.0f / s;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int d = (c * 64 + lane) * V + e;
+      r.v[c][e] = (r.v[c][e] * inv - (d == t ? 1.0f : 0.0f)) * scale;
+    }
+  r.store(glogits + (size_t)row * D, D, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Lion / SparseLion step for up to PP_OPT_MAX_TENSORS parameters in one launch
 // (lion_pytorch.Lion as the reference's optimizer configs name it, and high-order-layers-torch's
 // SparseLion = Lion that leaves entries with a zero gradient untouched; the Python restatement
@@ -328,6 +446,41 @@ hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int
 hipError_t pp_launch_max_abs_bwd_y(const float* y, const float* gy, const float* den,
                                    const int32_t* amax, float* gx, int B, int D, hipStream_t st) {
   PP_NORM_DISPATCH(pp_max_abs_bwd_y_kernel, y, gy, den, amax, gx, B, D);
+}
+
+// dispatch with an explicit grid (the forward walks the rows with a fixed number of blocks)
+#define PP_NORM_DISPATCH_GRID(KERNEL, GRID, ...)                                            \
+  do {                                                                                      \
+    const int V = (D % 4 == 0) ? 4 : (D % 2 == 0 ? 2 : 1);                                  \
+    const int need = (D + 64 * V - 1) / (64 * V);                                           \
+    dim3 grid(GRID), block(256);                                                            \
+    if (V == 4 && need <= 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 4 && need <= 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 4 && need <= 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 2) hipLaunchKernelGGL((KERNEL<2, 2>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 4) hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 2 && need <= 8) hipLaunchKernelGGL((KERNEL<2, 8>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 1 && need <= 4) hipLaunchKernelGGL((KERNEL<1, 4>), grid, block, 0, st, __VA_ARGS__); \
+    else if (V == 1 && need <= 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, block, 0, st, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                       \
+  } while (0)
+
+size_t pp_ce_workspace_bytes() { return (size_t)kCeBlocks * sizeof(float2); }
+
+hipError_t pp_launch_ce_fwd(const float* logits, const long* target, float* out, void* ws, int B,
+                            int D, hipStream_t st) {
+  const int nblk = std::min(kCeBlocks, (B + 3) / 4);
+  float2* part = static_cast<float2*>(ws);
+  PP_NORM_DISPATCH_GRID(pp_ce_fwd_kernel, nblk, logits, target, part, B, D);
+  hipLaunchKernelGGL(pp_ce_finish_kernel, dim3(1), dim3(256), 0, st, (const float2*)part, nblk, out,
+                     1.0f / (float)B);
+  return hipGetLastError();
+}
+
+hipError_t pp_launch_ce_bwd(const float* logits, const long* target, const float* gout,
+                            float* glogits, int B, int D, hipStream_t st) {
+  PP_NORM_DISPATCH_GRID(pp_ce_bwd_kernel, (B + 3) / 4, logits, target, gout, glogits, B, D);
+  return hipGetLastError();
 }
 
 hipError_t pp_launch_lion(int count, float* const* p, const float* const* g, float* const* m,

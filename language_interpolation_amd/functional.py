@@ -548,6 +548,55 @@ def max_abs_norm_last(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     return x / (x.abs().max(dim=-1, keepdim=True)[0] + eps)
 
 
+class CrossEntropyAccuracyFunction(torch.autograd.Function):
+    """(mean cross entropy, arg-max accuracy) of logits [B, C] against class indices [B]: one
+    kernel over the logits plus a fixed-order sum (csrc/pp_norm.hip); the backward recomputes the
+    softmax.  What ASCIIPredictionNet.eval_step computes (networks.py:121-132)."""
+
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, target: torch.Tensor):
+        lib = _lib.load()
+        _require_gpu(logits, "logits")
+        logits = logits.contiguous()
+        target = target.contiguous()
+        B, C = logits.shape
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        nbytes = lib.pp_cross_entropy_workspace_bytes()
+        ws = torch.empty(nbytes, device=logits.device, dtype=torch.uint8)
+        with torch.cuda.device(logits.device):
+            rc = lib.pp_cross_entropy_fwd_f32(_ptr(logits), _ptr(target), _ptr(out), _ptr(ws), nbytes,
+                                              B, C, _stream(logits.device))
+        _lib.check(rc, "pp_cross_entropy_fwd_f32")
+        ctx.save_for_backward(logits, target)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc):
+        lib = _lib.load()
+        logits, target = ctx.saved_tensors
+        B, C = logits.shape
+        g = gloss.reshape(1).to(torch.float32).contiguous()
+        glogits = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            rc = lib.pp_cross_entropy_bwd_f32(_ptr(logits), _ptr(target), _ptr(g), _ptr(glogits), B,
+                                              C, _stream(logits.device))
+        _lib.check(rc, "pp_cross_entropy_bwd_f32")
+        return glogits, None
+
+
+def cross_entropy_accuracy(logits: torch.Tensor, target: torch.Tensor):
+    """(loss, accuracy) as `CrossEntropyLoss()(logits, target)` and
+    `(argmax(logits, 1) == target).float().mean()`; logits [B, C] fp32, target int64 [B]."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and \
+            1 <= logits.shape[1] <= NORM_MAX_D and logits.shape[0] > 0 and \
+            target.dtype == torch.int64:
+        return CrossEntropyAccuracyFunction.apply(logits, target)
+    loss = torch.nn.functional.cross_entropy(logits, target)
+    return loss, (torch.argmax(logits, dim=1) == target).float().mean()
+
+
 class SelectiveScanFunction(torch.autograd.Function):
     """Mamba's selective scan (state_space_network.py:372-420 of the reference) as one HIP
     kernel per direction; the forward keeps every state x_t for the backward."""

@@ -33,6 +33,7 @@ from typing import Any, Dict, Iterable, Optional
 import torch
 import torch.nn as nn
 
+from . import functional as PF
 from .layers import (LazyLayerNormLastDim, MaxAbsNormalizationLast, MaxCenterNormalizationLast,
                      high_order_fc_layers)
 from .networks import HighOrderMLP, LowOrderMLP
@@ -282,9 +283,8 @@ class ASCIIPredictionNet(nn.Module):
     def eval_step(self, batch):
         x, y = batch[0], batch[1]
         y_hat = self(x)
-        loss = self.loss(y_hat, y.flatten())
-        accuracy = (torch.argmax(y_hat, dim=1) == y.flatten()).float().mean()
-        return loss, accuracy
+        # (CrossEntropyLoss + argmax accuracy; one HIP kernel per direction on the GPU)
+        return PF.cross_entropy_accuracy(y_hat, y.flatten())
 
     def configure_optimizers(self, capturable: bool = False):
         """`capturable`: keep Adam's step count on the device (needed under HIP graph capture)."""
@@ -304,9 +304,7 @@ class MambaASCIIPredictionNet(ASCIIPredictionNet):
     def eval_step(self, batch):
         x, y = batch[0], batch[1]
         y_hat = self(x)
-        loss = self.loss(y_hat.reshape(y.shape[0] * y.shape[1], -1), y.flatten())
-        accuracy = (torch.argmax(y_hat, dim=2, keepdim=True) == y).float().mean()
-        return loss, accuracy
+        return PF.cross_entropy_accuracy(y_hat.reshape(y.shape[0] * y.shape[1], -1), y.flatten())
 
 
 def prediction_net(cfg: Config, device=None) -> ASCIIPredictionNet:

@@ -196,3 +196,26 @@ def test_fused_lion_step_matches_the_torch_rule(sparse):
             assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=0, atol=1e-6), step
             mc, mg = opt_c.state[pc]["exp_avg"], opt_g.state[pg]["exp_avg"]
             assert torch.allclose(mg.cpu(), mc, rtol=1e-6, atol=1e-7), step
+
+
+@pytest.mark.parametrize("B,C", [(16384, 128), (1000, 128), (7, 5), (130, 1000), (3, 257), (1, 1)])
+def test_cross_entropy_accuracy_kernel_matches_torch(B, C):
+    """Loss, accuracy and the gradient of the fused kernel against torch's CrossEntropyLoss /
+    argmax in fp64 (networks.py:121-132 of the reference)."""
+    from language_interpolation_amd import functional as PF
+    g = torch.Generator().manual_seed(B + C)
+    logits = (4 * torch.randn(B, C, generator=g)).cuda().requires_grad_(True)
+    target = torch.randint(0, C, (B,), generator=g).cuda()
+    loss, acc = PF.cross_entropy_accuracy(logits, target)
+    ref_in = logits.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, target)
+    ref_acc = (torch.argmax(ref_in, dim=1) == target).double().mean()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert abs(acc.item() - ref_acc.item()) <= 1e-6
+    (3.0 * loss).backward()
+    (3.0 * ref).backward()
+    err = (logits.grad.double() - ref_in.grad).abs().max().item()
+    assert err <= 1e-6 * max(ref_in.grad.abs().max().item(), 1e-30) + 1e-12
+    # the same bits every time
+    loss2, acc2 = PF.cross_entropy_accuracy(logits.detach(), target)
+    assert torch.equal(loss2, loss.detach()) and torch.equal(acc2, acc)
