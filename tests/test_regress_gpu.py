@@ -489,3 +489,56 @@ def test_multi_layer_weight_pack_equals_per_layer_pack():
     PF._prepacked.clear()
     y2 = net.model(x)
     assert torch.allclose(y1, y2, rtol=0, atol=2e-6 * y2.abs().max().item())
+
+
+# batch sizes on both sides of every dispatch threshold of the small-batch work: one row per
+# block (<= 1024), the dense-regime layers' gather kernels (< 256 / < 384), PP_BWD_W_DIRECT
+# (<= 512), the f32-MFMA row chunking
+SWEEP_ROWS = [1, 63, 240, 255, 256, 383, 384, 512, 513, 1000, 1024, 1025, 2049]
+# (disc, n, S, I, O, dist): K = 258 > 192 (sort / direct), a many-segment hidden layer, two
+# dense-regime layers
+SWEEP_LAYERS = [(True, 2, 129, 16, 96, "char"), (False, 2, 40, 96, 96, "normal"),
+                (False, 3, 2, 96, 96, "normal"), (False, 3, 2, 96, 40, "normal")]
+
+
+@pytest.mark.parametrize("layer", SWEEP_LAYERS, ids=lambda c: "-".join(str(v) for v in c))
+def test_layer_parity_across_the_batch_size_thresholds(layer):
+    """y, gx, gw of the automatic method choice against the oracle at every batch size of
+    SWEEP_ROWS (the oracle takes its segment ids in fp32, as the kernels do)."""
+    disc, n, S, I, O, dist = layer
+    for B in SWEEP_ROWS:
+        x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=300 + B % 97)
+        check(hip_all(x, w, gy, n, S, disc), oracle_all(x, w, gy, n, S, disc), f"rows={B}")
+
+
+@pytest.mark.parametrize("norm", ["layer", "maxabs"])
+def test_network_output_across_the_batch_size_thresholds(norm):
+    """HighOrderMLP (layer+norm pairs fused where the layer has the kernel) against the fp64
+    oracle network at every batch size of SWEEP_ROWS.  Outputs only: they are continuous in
+    every activation, whereas a gradient through a piecewise-linear layer jumps when an
+    activation sits within rounding of a segment edge (the per-layer test above covers the
+    gradients, on shared inputs)."""
+    import language_interpolation_amd as lia
+    from oracle import pp_oracle as po
+    torch.manual_seed(11)
+    kw = dict(layer_type="continuous", n=3, n_in=2, n_hidden=3, in_width=16, in_segments=129,
+              hidden_width=96, hidden_segments=2, hidden_layers=2, out_width=40, out_segments=2)
+    hip_norm = lia.LazyLayerNormLastDim if norm == "layer" else lia.MaxAbsNormalizationLast
+    ora_norm = po.OracleLazyLayerNormLastDim if norm == "layer" else po.OracleMaxAbsNormalizationLast
+    net = lia.HighOrderMLP(normalization=hip_norm, device="cuda", **kw)
+    ora = po.OracleHighOrderMLP(normalization=ora_norm, **kw).double()
+    with torch.no_grad():
+        for a, b in zip(ora.parameters(), net.parameters()):
+            a.copy_(b.detach().cpu().double())
+    g = torch.Generator().manual_seed(12)
+    for B in SWEEP_ROWS:
+        x = torch.rand(B, 16, generator=g) * 2.2 - 1.1
+        with torch.no_grad():
+            y = net(x.cuda())
+            yo = ora(x.double())
+        assert rel_err(y.cpu().double(), yo) <= 5 * TOL, (norm, B)
+        # ... and the same bits as the modules run one at a time where the fused kernel is the
+        # gather kernel (every layer under 384 rows)
+        if B < 384:
+            with torch.no_grad():
+                assert torch.equal(net.model(x.cuda()), y), (norm, B)
