@@ -104,16 +104,19 @@ def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=
                                    1.0, 0, st)
 
     methods = [lib.pp_auto_method(p, B, I, O, n, S, d, 2.0) for p in range(3)]
-    if prepacked and methods[0] == _lib.FWD_FP16X2 and methods[1] == _lib.BWD_X_FP16X2:
+    if prepacked and methods[1] == _lib.BWD_X_FP16X2:
         # the way a training step runs them: weights pre-split once per step
-        # (pp_pack_weights_multi_f32), forward and backward-input are one kernel each
+        # (pp_pack_weights_multi_f32), forward and backward-input are one kernel each (just
+        # above the matrix-core threshold the forward is the gather kernel and only the
+        # backward-input reads the pre-split buffer)
         packed = PF.pack_weights(w_t, spec, B)
         pk = packed.numel()
         PRE = 0x100  # PP_WS_PREPACKED
 
-        def fwd():  # noqa: F811
-            lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(packed), pk, B, I, O, n, S, d, 2.0,
-                                  nodes, 1.0, _lib.FWD_FP16X2 | PRE, st)
+        if methods[0] == _lib.FWD_FP16X2:
+            def fwd():  # noqa: F811
+                lib.pp_forward_ws_f32(P(x), P(w_t), P(y), None, P(packed), pk, B, I, O, n, S, d,
+                                      2.0, nodes, 1.0, _lib.FWD_FP16X2 | PRE, st)
 
         def bwd_x():  # noqa: F811
             lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(packed), pk, B, I, O, n, S,

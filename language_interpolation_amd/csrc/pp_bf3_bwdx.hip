@@ -305,7 +305,7 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
 }
 
 template <class SC, int N, int K, int RM>
-__global__ __launch_bounds__(256) void pp_bwd_x_bf3_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256, (RM == 1 && K <= 5) ? 2 : 1) void pp_bwd_x_bf3_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ gy,
                                                            const void* __restrict__ Q,
                                                            float* __restrict__ gx, PPShape sh,
@@ -366,8 +366,11 @@ hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, 
   dc.inv_w = (float)sh.S / 2.0f;
   dc.inv_len = 1.0f / sh.length;
   if (!prepacked) pack_wo_split<SC>(wt, ws, q_off, sh, true, st);
-  // 64-row tiles keep K*2 accumulators per wave: K <= 6 (registers); else 32-row tiles
-  int rm = sh.B >= 4096 && sh.K <= 5 ? 2 : 1;  // K = 6 at 64 rows spills hundreds of registers
+  // 32-row tiles: with K <= 5 they fit 256 registers (__launch_bounds__(256, 2) on the kernel),
+  // so two workgroups share a CU and hide each other's round trips -- 44 vs 53 us at 16384
+  // rows, 15 vs 24 at 4096 on the cfg2 hidden layer against the 64-row tiles, which hold
+  // 256 + 256 registers and run one workgroup per CU (they remain for the developer override)
+  int rm = 1;
 #ifdef PP_TUNING  // developer builds only
   if (const char* v = getenv("PP_BF3_BWDX_RM")) {
     const int c = atoi(v);
