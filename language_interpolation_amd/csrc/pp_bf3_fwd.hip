@@ -60,7 +60,7 @@ __device__ __forceinline__ void fwd_tile_fp32(const float* __restrict__ x, const
 }
 
 template <class SC, int N, int K, int RM, int NT, int G>
-__global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ? 4 : 1) void pp_fwd_bf3_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ wt,
                                                              const void* __restrict__ ws,
                                                              float* __restrict__ y, PPShape sh,
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256 * G) void pp_fwd_bf3_kernel(const float* __rest
   // two sets in ping-pong, one k-step ahead.
   // When K sets do not fit the register budget of two waves per SIMD: two sets in
   // ping-pong over the flattened (step, k) sequence instead (one k-step ahead).
-  constexpr bool RING = K * PL * NT * 4 <= 96;
+  // (32-row tiles at K = 5: two sets, so that two workgroups fit a CU -- see the launch rule)
+  constexpr bool RING = K * PL * NT * 4 <= 96 && !(RM == 1 && NT == 2 && K == 5);
   constexpr int NW = RING ? K : 2;
   frag W[NW][PL][NT], A[2][RM][PL];
   if constexpr (RING) {
@@ -441,8 +442,12 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
   dc.inv_len = 1.0f / sh.length;
   if (!prepacked) pack_w_split<SC>(wt, ws, sh, true, st);
   // variant: 64-row tiles once they fill the chip (K <= 6: two groups' basis buffers fit
-  // LDS); waves of 32 outs when O <= 128 so all four column waves have work.
-  int rm = sh.B >= 8192 && sh.K <= 6 ? 2 : 1;
+  // LDS); waves of 32 outs when O <= 128 so all four column waves have work.  Below 16384
+  // rows the 64-row tiles leave CUs idle (8192 rows: 128 workgroups) and the 32-row variant
+  // runs two workgroups per CU (for K = 5 that takes the two-set W ping-pong instead of the
+  // K-set ring: 90 registers instead of 154) -- 25 vs 34 us at 8192 rows, 18.5 vs 20.3 at
+  // 1000 on the cfg2 hidden layer; at 16384 rows and above the 64-row tiles win (39 vs 41).
+  int rm = sh.B >= 16384 && sh.K <= 6 ? 2 : 1;
   int nt = sh.O > 128 ? 2 : 1;
 #ifdef PP_TUNING  // developer builds only: PP_BF3_VARIANT=<rm><nt>
   if (const char* v = getenv("PP_BF3_VARIANT")) {
