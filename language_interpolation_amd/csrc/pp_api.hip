@@ -131,7 +131,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
                        ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
                        : PP_BWD_X_GATHER;
     case 2:
-      if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 8192 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
+      if (dense) return pp_bf3_bwd_w_supported(sh) && B >= 4096 ? PP_BWD_W_FP16X2 : PP_BWD_W_DENSE;
       if (pp_regacc_preferred(sh)) return PP_BWD_W_REGACC;
       if (pp_regacc_supported(sh)) return PP_BWD_W_ATOMIC;  // too small for anything but atomics
       // more weight rows per input than the register accumulators hold, at the reference's
