@@ -7,7 +7,8 @@ and tensor shapes.  The four projections of a block are ``HighOrderMLP`` (two pi
 polynomial layers each: the hot path) unless ``layer_type == "linear"``; the time loop of
 ``selective_scan`` (:372-420) is one HIP kernel per direction (csrc/pp_scan.hip); the causal
 depthwise conv + SiLU, the gate ``y * silu(res)`` and RMSNorm are one HIP kernel per direction
-each (csrc/pp_mamba.hip).  Embedding, softplus and lm_head stay torch ops (one kernel each).
+each (csrc/pp_mamba.hip).  Embedding, softplus and lm_head stay torch ops; the weight gradients of
+the (tied) embedding and head are computed as split-K batched products (_tn_matmul).
 """
 from __future__ import annotations
 
@@ -46,6 +47,58 @@ def causal_depthwise_conv(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.
     for j in range(1, k):
         y = y + xp[:, j:j + l] * w[:, j]
     return y if bias is None else y + bias
+
+
+def _tn_matmul(a: torch.Tensor, b: torch.Tensor, chunk: int = 256) -> torch.Tensor:
+    """a^T @ b for a [M, p], b [M, q] with M >> p, q: the rows are cut into chunks, one batched
+    matmul gives a [p, q] product per chunk and the chunks are added.  (rocBLAS runs the plain
+    [p, M] x [M, q] product of the tied head's weight gradient -- 128 x 15360 x 64 at b = 1024 -- as
+    a handful of tiles walking all M rows: 109 us; this way 10.)"""
+    M = a.shape[0]
+    if M <= 2 * chunk:
+        return a.t() @ b
+    pad = (-M) % chunk
+    if pad:
+        a = F.pad(a, (0, 0, 0, pad))
+        b = F.pad(b, (0, 0, 0, pad))
+    c = a.shape[0] // chunk
+    return torch.bmm(a.view(c, chunk, -1).transpose(1, 2), b.view(c, chunk, -1)).sum(0)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """logits = x @ W^T (the tied lm_head, state_space_network.py:90-93, :118) with the weight gradient
+    as a split-K product."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        x2, g2 = x.reshape(-1, x.shape[-1]), g.reshape(-1, g.shape[-1])
+        gx = (g2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = _tn_matmul(g2, x2) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _EmbeddingFunction(torch.autograd.Function):
+    """embedding(ids) with the weight gradient as one_hot(ids)^T @ g through the same split-K
+    product (torch's embedding backward sorts the indices and scatters: 80 us at b = 1024 for a
+    128-row table; deterministic either way)."""
+
+    @staticmethod
+    def forward(ctx, ids, w):
+        ctx.save_for_backward(ids)
+        ctx.rows = w.shape[0]
+        return F.embedding(ids, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        onehot = F.one_hot(ids.reshape(-1), ctx.rows).to(g.dtype)
+        return None, _tn_matmul(onehot, g.reshape(-1, g.shape[-1]))
 
 
 class RMSNorm(nn.Module):
@@ -133,7 +186,9 @@ class Mamba(nn.Module):
 
     def forward(self, input_ids):
         """input_ids: long [b, l, 1] (or [b, l]) -> logits [b, l, vocab]."""
-        x = self.embedding(input_ids.reshape(input_ids.shape[0], -1))
+        ids = input_ids.reshape(input_ids.shape[0], -1)
+        # (same results as self.embedding(ids) / self.lm_head(...): the weight is tied)
+        x = _EmbeddingFunction.apply(ids, self.embedding.weight)
         for layer in self.layers:
             x = layer(x)
-        return self.lm_head(self.norm_f(x))
+        return _HeadFunction.apply(self.norm_f(x), self.lm_head.weight)

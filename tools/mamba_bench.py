@@ -1,4 +1,5 @@
-"""Selective scan and Mamba (cfg5) timings: python tools/mamba_bench.py [b]"""
+"""Selective scan and Mamba (cfg5) timings: python tools/mamba_bench.py [b]
+(PP_MB_OPT=adam for Adam instead of the reference's default optimizer, sparse_lion)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -54,7 +55,8 @@ for name, f in (() if os.environ.get("PP_MB_ONLY") else (("hip", PF.selective_sc
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = T.load_config(os.path.join(root, "configs", "high_order_interpolation.yaml"),
-                    ["net=mamba", "net.n_layer=2", "optimizer=adam", f"batch_size={b}", "data.max_features=16"])
+                    ["net=mamba", "net.n_layer=2", f"optimizer={os.environ.get('PP_MB_OPT', 'sparse_lion')}",
+                     f"batch_size={b}", "data.max_features=16"])
 data = T.make_data(cfg, T.synthetic_text(1 << 20))
 VARIANTS = ("hip scan, graph replay", "hip scan", "torch-loop scan")
 if os.environ.get("PP_MB_ONLY"):
