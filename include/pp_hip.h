@@ -259,6 +259,16 @@ int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* de
 int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
                               const int32_t* amax, float* gx, int B, int D, void* stream);
 
+/* A batch of character windows from the text held on the device as one uint8 buffer (what
+ * generate_dataset + the DataLoader collate of the reference produce on the host:
+ * single_text_dataset.py:102-123 and :15-16, lightning_datamodule.py:272-291).  Window b starts at
+ * text[idx[b]] (clamped into the text) and has features + 1 characters.  Outputs, each optional
+ * (NULL):  x[B][features] = (c + 0.5 - 64) / 64 of the first `features` characters;
+ * y[B] = the last character (the target of the MLP models);  tokens[B][features + 1] = all of
+ * them as int64 (the Mamba model's indices: inputs = [:, :-1], targets = [:, 1:]). */
+int pp_char_windows(const uint8_t* text, int64_t text_len, const int64_t* idx, int B, int features,
+                    float* x, int64_t* tokens, int64_t* y, void* stream);
+
 /* Cross entropy of logits[B][C] (C <= 1024) against int64 class indices with the arg-max accuracy,
  * as ASCIIPredictionNet.eval_step computes them (networks.py:121-132: CrossEntropyLoss, mean
  * reduction; accuracy = mean(argmax == target)): loss_acc[0] = mean loss, loss_acc[1] = accuracy.

@@ -565,6 +565,16 @@ int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
   return hip_rc(pp_launch_max_abs_bwd_y(y, gy, den, amax, gx, B, D, (hipStream_t)stream));
 }
 
+int pp_char_windows(const uint8_t* text, int64_t text_len, const int64_t* idx, int B, int features,
+                    float* x, int64_t* tokens, int64_t* y, void* stream) {
+  if (!text || !idx || (!x && !tokens && !y)) return PP_ERR_NULL;
+  if (B < 1 || features < 1 || text_len < (int64_t)features + 1) return PP_ERR_SHAPE;
+  if ((int64_t)B * (features + 1) >= (1LL << 40)) return PP_ERR_RANGE;
+  return hip_rc(pp_launch_char_windows(text, (long)text_len, reinterpret_cast<const long*>(idx), B,
+                                       features, x, reinterpret_cast<long*>(tokens),
+                                       reinterpret_cast<long*>(y), (hipStream_t)stream));
+}
+
 size_t pp_cross_entropy_workspace_bytes(void) { return pp_ce_workspace_bytes(); }
 
 int pp_cross_entropy_fwd_f32(const float* logits, const int64_t* target, float* loss_acc,

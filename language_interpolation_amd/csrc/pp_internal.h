@@ -77,6 +77,8 @@ hipError_t pp_launch_layer_norm_bwd(const float* y, const float* gy, const float
 hipError_t pp_launch_max_abs_fwd(const float* x, float* y, int B, int D, float eps, hipStream_t st);
 hipError_t pp_launch_max_abs_bwd(const float* x, const float* gy, float* gx, int B, int D, float eps,
                                  hipStream_t st);
+hipError_t pp_launch_char_windows(const uint8_t* text, long text_len, const long* idx, int B, int F,
+                                  float* x, long* tokens, long* y, hipStream_t st);
 size_t pp_ce_workspace_bytes();
 hipError_t pp_launch_ce_fwd(const float* logits, const long* target, float* out, void* ws, int B,
                             int D, hipStream_t st);

@@ -320,6 +320,21 @@ def ascii_to_float(c: torch.Tensor) -> torch.Tensor:
     return (c - 64 + 0.5) / 64
 
 
+def _char_windows(buf, idx, features, x, tokens, y):
+    """pp_char_windows on the current stream of buf's device (idx: int64 window starts)."""
+    from . import _lib
+    lib = _lib.load()
+    idx = idx.contiguous()
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    if idx.numel() == 0:
+        return
+    with torch.cuda.device(buf.device):
+        rc = lib.pp_char_windows(PF._ptr(buf), buf.numel(), PF._ptr(idx), idx.numel(), features,
+                                 PF._ptr(x), PF._ptr(tokens), PF._ptr(y), PF._stream(buf.device))
+    _lib.check(rc, "pp_char_windows")
+
+
 class CharWindows:
     """All windows of ``features`` characters + the next one as target, held as ONE uint8
     buffer on the device; a batch is an index gather (what generate_dataset builds as
@@ -340,6 +355,12 @@ class CharWindows:
 
     def batch(self, idx: torch.Tensor):
         idx = idx.to(self.buf.device)
+        if self.buf.is_cuda:  # one kernel: gather, normalise, targets (csrc/pp_data.hip)
+            B = idx.numel()
+            x = torch.empty(B, self.features, device=self.buf.device, dtype=torch.float32)
+            y = torch.empty(B, 1, device=self.buf.device, dtype=torch.int64)
+            _char_windows(self.buf, idx, self.features, x, None, y)
+            return x, y, idx
         win = self.buf[idx.unsqueeze(1) + self._ar]
         x = ascii_to_float(win.float())
         y = self.buf[idx + self.features].long().unsqueeze(1)
@@ -363,8 +384,13 @@ class CharSequences(CharWindows):
 
     def batch(self, idx: torch.Tensor):
         idx = idx.to(self.buf.device)
-        win = self.buf[idx.unsqueeze(1) + torch.arange(self.features + 1, device=self.buf.device)]
-        win = win.long().unsqueeze(2)
+        if self.buf.is_cuda:
+            win = torch.empty(idx.numel(), self.features + 1, device=self.buf.device,
+                              dtype=torch.int64)
+            _char_windows(self.buf, idx, self.features, None, win, None)
+        else:
+            win = self.buf[idx.unsqueeze(1) + torch.arange(self.features + 1)].long()
+        win = win.unsqueeze(2)
         return win[:, :-1], win[:, 1:], idx
 
 
