@@ -102,8 +102,8 @@ class GradAllReducer:
 class GraphedGradAllReduce:
     """Gradient exchange for a step whose forward+backward is replayed from a HIP graph: the
     gradients then live in the graph's static buffers, so after each replay they are summed
-    over the ranks in place -- large ones on their physical storage, small ones through one
-    flat bucket -- and scaled by 1/world.  No hooks (nothing of autograd runs at replay)."""
+    over the ranks through one flat bucket and scaled by 1/world, in place.  No hooks (nothing of
+    autograd runs at replay)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
                  small_numel: int = 65536, average: bool = True):
@@ -116,34 +116,31 @@ class GraphedGradAllReduce:
     def __call__(self) -> None:
         if self.world <= 1:
             return
-        small = []
+        # ONE bucket: every gradient's storage-order view copied into a flat buffer, one
+        # all-reduce, one scale, one multi-tensor copy back -- a collective per parameter
+        # costs its launch latency five times a step for these 0.6-2 MB tensors.  (small_numel
+        # is kept for the constructor's signature; everything shares the bucket.)
+        views = []
         for p in self.params:
             g = p.grad
             if g is None:
                 continue
-            if g.numel() < self.small_numel:
-                small.append(g)
-                continue
             v = _physical_view(g)
-            back = None
-            if not v.is_contiguous():
-                back, v = g, g.contiguous()
-            # plain stream-ordered collectives: RCCL enqueues on its own stream and the
-            # current stream waits for it
-            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
-            if self.scale != 1.0:
-                v.mul_(self.scale)
-            if back is not None:
-                back.copy_(v)
-        if small:
-            flat = torch.cat([g.reshape(-1) for g in small])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.scale != 1.0:
-                flat.mul_(self.scale)
-            off = 0
-            for g in small:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            if not v.is_contiguous():  # no storage-order view: reduce a copy, write it back
+                c = g.contiguous()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(c.mul_(self.scale) if self.scale != 1.0 else c)
+                continue
+            views.append(v.reshape(-1))
+        if not views:
+            return
+        flat = torch.cat(views)
+        # plain stream-ordered collective: RCCL enqueues on its own stream and the current
+        # stream waits for it
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.scale != 1.0:
+            flat.mul_(self.scale)
+        torch._foreach_copy_(views, list(flat.split([v.numel() for v in views])))
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None) -> None:
