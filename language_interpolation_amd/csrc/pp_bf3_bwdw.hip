@@ -272,12 +272,40 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
   auto stepfn = [&](int t, auto jc) {
     constexpr int J = decltype(jc)::value;
     if constexpr (SC::kRanged) rescale(t);
+    // (PP_NO_*: developer ablations of tools/bwdw_timing.hip -- wrong results, timing only)
+#ifndef PP_NO_XLOAD
     xload(t + 3, xr[(J + 1) & 1]);
+#endif
+#ifndef PP_NO_BLOAD
     bload(t + 2, Bf[(J + 2) % 3]);
+#endif
+#ifndef PP_NO_ALOAD
     aload((J + 1) % 3, A[(J + 1) & 1]);
+#endif
+#ifndef PP_NO_PRODUCE
     produce(t + 2, (J + 2) % 3, xr[J & 1]);
+#endif
+#ifndef PP_NO_MFMA
     mm(A[J & 1], Bf[J % 3]);
+#endif
+    // One wave per SIMD here (256 + 220 registers), so nothing but the wave's own instruction
+    // order overlaps the basis evaluation with the MFMAs: left alone the compiler interleaves
+    // the first 13 of a step's 30 MFMAs with the VALU work and issues the other 17 back to
+    // back behind the barrier.  Groups of one MFMA + four VALU spread them over the whole
+    // step: 53.4 -> 50.1 us per call at 16384 rows (tools/bwdw_timing.hip; 2 / 3 / 5 / 6 VALU
+    // per group: 54.1 / 51.9 / 51.1 / 52.1).
+    // (Two-tile waves only: with one tile there are ten VALU per MFMA and the groups bought
+    // nothing -- 27 vs 30 us on the 250 -> 128 layer at 4096 rows.)
+    if constexpr (NT == 2) {
+#pragma unroll
+      for (int i = 0; i < K * SC::NC * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four VALU under it
+      }
+    }
+#ifndef PP_NO_BARRIER
     __syncthreads();
+#endif
   };
   for (int t = 0; t < nst; t += 6) {
     stepfn(t, std::integral_constant<int, 0>{});
@@ -304,7 +332,12 @@ __global__ __launch_bounds__(256) void pp_bwd_w_bf3_kernel(const float* __restri
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;  // input index
-            if (row < sh.I) dst[((size_t)row * K + k) * sh.O + col] = acc[k][nt][q] * cs;
+#ifdef PP_NO_STORE  // (ablation: one store per tile keeps the accumulators alive)
+            if (row < sh.I && acc[k][nt][q] * cs == 12345.678f)
+#else
+            if (row < sh.I)
+#endif
+              dst[((size_t)row * K + k) * sh.O + col] = acc[k][nt][q] * cs;
           }
       }
     }
