@@ -201,6 +201,12 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
   constexpr int D = 1;
   constexpr int NWS = 2 * D;
   frag W[NWS][K][PL], A[2][RM][PL];
+  // the packed weights' scale: read here (scalar loads, one register), used by the epilogue
+  float wsinv = 1.0f;
+  if constexpr (SC::kRanged) {
+    float sc;
+    h2_scale(absmax_of_parts(ws), sc, wsinv);
+  }
   gy_load(0);
 #pragma unroll
   for (int u = 0; u < D; ++u) wload(u, W[u]);
@@ -260,11 +266,6 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
     if (more) gy_publish(c + 1, buf ^ 1);
     __syncthreads();
     PP_TICK(4 + 2 * (c & 1))
-  }
-  float wsinv = 1.0f;
-  if constexpr (SC::kRanged) {
-    float sc;
-    h2_scale(absmax_of_parts(ws), sc, wsinv);
   }
   const int lastbuf = (nchunk - 1) & 1;
 

@@ -196,6 +196,13 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
   constexpr bool RING = K * PL * NT * 4 <= 96 && !(RM == 1 && NT == 2 && K == 5);
   constexpr int NW = RING ? K : 2;
   frag W[NW][PL][NT], A[2][RM][PL];
+  // the packed weights' scale: read here (scalar loads, one register), used by the epilogue
+  float oscale = sh.out_scale;
+  if constexpr (SC::kRanged) {
+    float sc, inv;
+    h2_scale(absmax_of_parts(ws), sc, inv);
+    oscale *= inv;
+  }
   if constexpr (RING) {
 #pragma unroll
     for (int k = 0; k < K; ++k) wload(g, k, W[k]);
@@ -249,12 +256,6 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
   // below instead of being stored (decided before any store, so the two never overlap)
   bool bad = false;
   if constexpr (SC::kRanged) bad = __syncthreads_or(!(lmax <= kH2Limit));
-  float oscale = sh.out_scale;
-  if constexpr (SC::kRanged) {
-    float sc, inv;
-    h2_scale(absmax_of_parts(ws), sc, inv);
-    oscale *= inv;
-  }
   // accumulator tiles of this wave: tix = rm*NT + nt.  With two groups, group g finishes
   // the tiles with tix % 2 == g (all of them in group 0 when there is only one) and hands
   // the others to the partner wave (same cw, other group) through LDS (the basis buffers

@@ -1,0 +1,208 @@
+"""Randomised parity run of the HIP path against the oracle (test infrastructure, not collected
+by pytest: run it by name on a GPU box).
+
+    python tests/fuzz_parity.py --seconds 300 --seed 1 [--out gpurun_out/fuzz/fails.txt]
+
+Every case draws a layer shape (n, segments, continuous / discontinuous, in, out), a batch size
+around the dispatch thresholds and an input distribution, runs forward, backward-input and
+backward-weight with the library's own method choice ("auto") through the C-ABI, and checks them
+against oracle/pp_oracle.py in fp64 to the north_star bar (segment ids bit-exact, 1e-5 of the
+tensor's largest magnitude); --forced adds a leg with one forced method per direction.
+`draw_case` and `run_case` are shared with tests/test_regress_gpu.py, which runs a fixed,
+seeded slice of the same distribution.  The case being run is kept in <out>.current, so that
+a run that dies names its case.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ROWS = [1, 2, 31, 64, 100, 255, 256, 257, 383, 384, 500, 512, 513, 777, 1000, 1024, 1025, 1500,
+        2048, 2049, 3000, 4096, 4097]
+SEGMENTS = [1, 2, 2, 2, 3, 4, 5, 8, 16, 37, 128, 150]
+WIDTHS = [1, 3, 4, 15, 16, 17, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 129, 200, 250, 256, 300]
+DISTS = ["normal", "uniform", "char", "edges"]
+BUDGET = 6e7  # rows * in * n * out elements of the oracle's gathered fp64 tensor
+
+
+def draw_case(rng: random.Random):
+    """(disc, n, S, I, O, B, dist, seed) within the oracle's memory budget."""
+    while True:
+        disc = rng.random() < 0.4
+        n = rng.choice([1, 2, 2, 3, 3, 4, 5, 6, 7, 8]) if disc else rng.choice([2, 2, 3, 3, 4, 5, 6, 7, 8])
+        S = rng.choice(SEGMENTS)
+        I, O, B = rng.choice(WIDTHS), rng.choice(WIDTHS), rng.choice(ROWS)
+        if B * I * n * O <= BUDGET:
+            return disc, n, S, I, O, B, rng.choice(DISTS), rng.randrange(1 << 30)
+
+
+FWD = ["gather", "dense", "bf16x3", "fp16x2", "slab"]
+BWD_X = ["gather", "dense", "bf16x3", "fp16x2"]
+BWD_W = ["atomic", "sort", "dense", "bf16x3", "fp16x2", "regacc", "direct"]
+
+
+def abs_sums(x, w, gy, n, S, disc):
+    """Largest sum of |terms| behind one element of y, gx and gw (fp64): the scale a rounding
+    error of an fp32 evaluation is proportional to.  It equals max |tensor| when nothing cancels."""
+    import torch
+    from oracle import pp_oracle as po
+
+    s = po.segment_ids(x, S)
+    xi = po.local_coordinate(x.double(), s, S).requires_grad_(True)
+    nodes = po.chebyshev_lobatto(n).double()
+    basis = po.lagrange_basis(xi, nodes)  # [n,B,I]
+    dbasis = torch.stack([torch.autograd.grad(basis[j].sum(), xi, retain_graph=True)[0]
+                          for j in range(n)]) if n > 1 else torch.zeros_like(basis)
+    B, I = x.shape
+    O, _, K = w.shape
+    idx = (s * po.weight_stride(n, disc)).unsqueeze(-1) + torch.arange(n).view(1, 1, n)
+
+    def expand(b):
+        return torch.zeros(B, I, K, dtype=torch.float64).scatter_add(
+            2, idx, b.detach().abs().permute(1, 2, 0))
+
+    phi, dphi = expand(basis), expand(dbasis) * (S * 1.0)  # dxi/dx = L/(2/S) = S at L = 2
+    wa, ga = w.double().abs(), gy.double().abs()
+    y = phi.reshape(B, I * K) @ wa.reshape(O, I * K).t()
+    gw = torch.einsum("bo,bik->oik", ga, phi)
+    gx = torch.einsum("bik,oik,bo->bi", dphi, wa, ga)
+    return {"y": y.max().item(), "gx": gx.max().item(), "gw": gw.max().item()}
+
+
+def _compare(got, ref, ref32, sums):
+    """(failures, ill_conditioned) for one result set.  A tensor beyond the bar counts as
+    ill-conditioned, not failing, when its absolute error is within the bar of the largest sum
+    of |terms| behind one element (sums, a callable: the result cancelled, e.g. a single output
+    near zero), or when the reference formulation evaluated in fp32 (ref32, a callable) is no
+    more than twice as close to the fp64 result (high-order polynomials extrapolated far
+    outside [-1, 1]: no fp32 evaluation reaches 1e-5 there)."""
+    import torch
+    from pp_testlib import TOL, rel_err
+
+    bad, soft = [], []
+    if "seg" in got and not torch.equal(got["seg"].long(), ref["seg"].long()):
+        bad.append("segment ids differ")
+    for key in ("y", "gx", "gw"):
+        if key not in got:
+            continue
+        if not torch.isfinite(got[key]).all():
+            bad.append(f"{key} not finite")
+            continue
+        r = ref[key]
+        if r.abs().max() == 0:
+            if got[key].abs().max() != 0:
+                bad.append(f"{key} non-zero where the reference is zero")
+            continue
+        e = rel_err(got[key], r)
+        if e <= TOL:
+            continue
+        e32 = rel_err(ref32()[key], r)
+        cancel = r.abs().max().item() / max(sums()[key], 1e-300)
+        ok = e <= 2 * e32 or e * cancel <= TOL
+        (soft if ok else bad).append(
+            f"{key} rel err {e:.3e} (fp32 reference: {e32:.3e}; max|ref| / max sum|terms| = {cancel:.2e})")
+    return bad, soft
+
+
+def run_case(case, rng=None):
+    """(failures, ill_conditioned): lists of strings, both empty when the case is at parity.
+    With rng, a second leg forces one randomly drawn method per direction (skipped where the
+    library refuses it for the shape)."""
+    import torch
+    from language_interpolation_amd._lib import PPHipError
+    from pp_testlib import make_inputs
+    from oracle import pp_oracle as po
+    from test_parity_gpu import _pf, hip_all
+
+    disc, n, S, I, O, B, dist, seed = case
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist=dist, seed=seed)
+    ref = po.piecewise_fwd_bwd(x, w, gy, n, S, disc, precision="f64")
+    cache = {}
+
+    def ref32():
+        if not cache:
+            cache.update(po.piecewise_fwd_bwd(x, w, gy, n, S, disc, precision="f32"))
+        return cache
+
+    scache = {}
+
+    def sums():
+        if not scache:
+            scache.update(abs_sums(x, w, gy, n, S, disc))
+        return scache
+
+    bad, soft = _compare(hip_all(x, w, gy, n, S, disc), ref, ref32, sums)
+    if rng is not None:
+        PF = _pf()
+        f, bx, bw = rng.choice(FWD), rng.choice(BWD_X), rng.choice(BWD_W)
+        spec = PF.make_spec(n, S, disc, fwd_method=f, bwd_x_method=bx, bwd_w_method=bw,
+                            in_features=I)
+        xd, gyd = x.cuda(), gy.cuda()
+        w_t = w.cuda().permute(1, 2, 0).contiguous()
+        got = {}
+        for key, name, call in (
+                ("y", f, lambda: PF.forward_raw(xd, w_t, spec)[0]),
+                ("gx", bx, lambda: PF.backward_input_raw(xd, gyd, w_t, spec)),
+                ("gw", bw, lambda: PF.backward_weight_raw(xd, gyd, tuple(w_t.shape), spec)
+                 .permute(2, 0, 1))):
+            try:
+                got[key] = call().cpu()
+            except PPHipError as e:
+                if "inapplicable" not in str(e):
+                    bad.append(f"{key}[{name}]: {e}")
+        torch.cuda.synchronize()
+        b2, s2 = _compare(got, ref, ref32, sums)
+        bad += [f"forced {f}/{bx}/{bw}: {m}" for m in b2]
+        soft += [f"forced {f}/{bx}/{bw}: {m}" for m in s2]
+    return bad, soft
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--forced", action="store_true", help="also force a random method per direction")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    mrng = random.Random(args.seed + 1) if args.forced else None
+    t0, done, fails, softs = time.time(), 0, 0, 0
+    out = open(args.out, "w") if args.out else None
+
+    def emit(line):
+        print(line, flush=True)
+        if out:
+            out.write(line + "\n")
+            out.flush()
+
+    while time.time() - t0 < args.seconds:
+        case = draw_case(rng)
+        if args.out:
+            with open(args.out + ".current", "w") as cur:
+                cur.write(f"{done} {case}\n")
+        bad, soft = run_case(case, mrng)
+        done += 1
+        if bad:
+            fails += 1
+            emit(f"FAIL {case}: {'; '.join(bad)}")
+        if soft:
+            softs += 1
+            emit(f"ILL-CONDITIONED {case}: {'; '.join(soft)}")
+        if done % 100 == 0:
+            print(f"[{time.time() - t0:6.0f} s] {done} cases, {fails} failing, {softs} ill-conditioned",
+                  flush=True)
+    emit(f"done: {done} cases, {fails} failing, {softs} ill-conditioned, "
+         f"seed {args.seed}, forced methods {bool(args.forced)}")
+    if out:
+        out.close()
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

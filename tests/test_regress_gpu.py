@@ -542,3 +542,20 @@ def test_network_output_across_the_batch_size_thresholds(norm):
         if B < 384:
             with torch.no_grad():
                 assert torch.equal(net.model(x.cuda()), y), (norm, B)
+
+
+def test_seeded_slice_of_the_randomised_parity_run():
+    """40 cases of tests/fuzz_parity.py's distribution (random layer shapes, batch sizes around
+    the dispatch thresholds, four input distributions; the automatic method choice and one forced
+    method per direction) against the oracle; the long run is `python tests/fuzz_parity.py --seconds N`."""
+    import random
+
+    import fuzz_parity
+    rng, mrng = random.Random(20261111), random.Random(20261112)
+    failures = []
+    for _ in range(40):
+        case = fuzz_parity.draw_case(rng)
+        bad, _ill_conditioned = fuzz_parity.run_case(case, mrng)
+        if bad:
+            failures.append((case, bad))
+    assert not failures, failures
