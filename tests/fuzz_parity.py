@@ -31,14 +31,22 @@ DISTS = ["normal", "uniform", "char", "edges"]
 BUDGET = 6e7  # rows * in * n * out elements of the oracle's gathered fp64 tensor
 
 
-def draw_case(rng: random.Random):
-    """(disc, n, S, I, O, B, dist, seed) within the oracle's memory budget."""
+LARGE_ROWS = [4096, 8191, 8192, 8193, 12000, 16383, 16384, 16400]
+
+
+def draw_case(rng: random.Random, large: bool = False):
+    """(disc, n, S, I, O, B, dist, seed) within the oracle's memory budget.  large: batch sizes
+    around the large-batch thresholds (8192, 16384 rows); the budget is then the fp64 oracle's
+    expanded basis [B, I, K] and its matrix product."""
     while True:
         disc = rng.random() < 0.4
         n = rng.choice([1, 2, 2, 3, 3, 4, 5, 6, 7, 8]) if disc else rng.choice([2, 2, 3, 3, 4, 5, 6, 7, 8])
         S = rng.choice(SEGMENTS)
-        I, O, B = rng.choice(WIDTHS), rng.choice(WIDTHS), rng.choice(ROWS)
-        if B * I * n * O <= BUDGET:
+        I, O = rng.choice(WIDTHS), rng.choice(WIDTHS)
+        B = rng.choice(LARGE_ROWS if large else ROWS)
+        K = n * S if disc else (n - 1) * S + 1
+        ok = (B * I * K <= 1.5e8 and B * I * K * O <= 2e10) if large else B * I * n * O <= BUDGET
+        if ok:
             return disc, n, S, I, O, B, rng.choice(DISTS), rng.randrange(1 << 30)
 
 
@@ -163,16 +171,70 @@ def run_case(case, rng=None):
     return bad, soft
 
 
+def run_fused(case):
+    """Failure strings for the layer+normalisation kernels (LayerNorm and max-abs epilogues) on
+    one case: forward and all gradients of the fused autograd function against the same two
+    modules run one after the other on the GPU (whose layer the main leg holds to the oracle),
+    and the forward against the fp64 oracle.  Skipped (None) where neither fusion applies or
+    the rows are too short for a meaningful variance."""
+    import torch
+    from pp_testlib import TOL, make_inputs, rel_err
+    from oracle import pp_oracle as po
+    from test_parity_gpu import _pf
+
+    disc, n, S, I, O, B, dist, seed = case
+    if O < 16:
+        return None
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist=dist, seed=seed)
+    spec = PF.make_spec(n, S, disc)
+    wd0 = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    bad, ran = [], False
+    for name, fusable, fused, plain, oracle_norm in (
+            ("layer_norm", PF.layer_norm_fusable, lambda a, b: PF.piecewise_poly_layer_norm(a, b, spec, 1e-5),
+             lambda a, b: PF.layer_norm_last(PF.piecewise_poly(a, b, spec), 1e-5),
+             lambda t: po.layer_norm_last_dim(t, 1e-5)),
+            ("max_abs", PF.max_abs_fusable, lambda a, b: PF.piecewise_poly_max_abs(a, b, spec, 1e-6),
+             lambda a, b: PF.max_abs_norm_last(PF.piecewise_poly(a, b, spec), 1e-6),
+             lambda t: po.max_abs_normalization_last(t, 1e-6))):
+        if not fusable(x.cuda(), wd0, spec):
+            continue
+        ran = True
+        res = []
+        for fn in (fused, plain):
+            xd = x.cuda().requires_grad_(True)
+            wd = wd0.detach().clone().requires_grad_(True)
+            y = fn(xd, wd)
+            y.backward(gy.cuda())
+            res.append((y.detach().cpu(), xd.grad.cpu(), wd.grad.cpu()))
+        for key, a, b, bar in zip(("y", "gx", "gw"), res[0], res[1], (5e-6, 5e-5, 5e-5)):
+            if not torch.isfinite(a).all():
+                bad.append(f"{name}: {key} not finite")
+            elif b.abs().max() > 0 and not rel_err(a, b) <= bar:
+                bad.append(f"{name}: {key} fused vs two modules {rel_err(a, b):.3e}")
+        yo = oracle_norm(po.piecewise_forward_f64(x.float(), w.double(), n, S, disc))
+        # (rows whose layer output is almost constant, or almost zero, amplify the layer's own
+        # rounding: the bar is the network test's 5 * TOL, rows with a tiny spread left out)
+        raw = po.piecewise_forward_f64(x.float(), w.double(), n, S, disc)
+        spread = raw.std(dim=1) if name == "layer_norm" else raw.abs().amax(dim=1)
+        keep = spread > 1e-2 * spread.median().clamp_min(1e-30)
+        if keep.any() and not rel_err(res[0][0][keep], yo[keep]) <= 5 * TOL:
+            bad.append(f"{name}: y vs oracle {rel_err(res[0][0][keep], yo[keep]):.3e}")
+    return bad if ran else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--forced", action="store_true", help="also force a random method per direction")
+    ap.add_argument("--fused", action="store_true", help="also the layer+normalisation kernels")
+    ap.add_argument("--large", action="store_true", help="batch sizes of 4096 .. 16400 rows")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     mrng = random.Random(args.seed + 1) if args.forced else None
-    t0, done, fails, softs = time.time(), 0, 0, 0
+    t0, done, fails, softs, nfused = time.time(), 0, 0, 0, 0
     out = open(args.out, "w") if args.out else None
 
     def emit(line):
@@ -182,11 +244,15 @@ def main():
             out.flush()
 
     while time.time() - t0 < args.seconds:
-        case = draw_case(rng)
+        case = draw_case(rng, args.large)
         if args.out:
             with open(args.out + ".current", "w") as cur:
                 cur.write(f"{done} {case}\n")
         bad, soft = run_case(case, mrng)
+        if args.fused:
+            fb = run_fused(case)
+            nfused += fb is not None
+            bad += fb or []
         done += 1
         if bad:
             fails += 1
@@ -194,11 +260,12 @@ def main():
         if soft:
             softs += 1
             emit(f"ILL-CONDITIONED {case}: {'; '.join(soft)}")
-        if done % 100 == 0:
+        if done % (10 if args.large else 100) == 0:
             print(f"[{time.time() - t0:6.0f} s] {done} cases, {fails} failing, {softs} ill-conditioned",
                   flush=True)
     emit(f"done: {done} cases, {fails} failing, {softs} ill-conditioned, "
-         f"seed {args.seed}, forced methods {bool(args.forced)}")
+         f"seed {args.seed}, forced methods {bool(args.forced)}, large batches {bool(args.large)}"
+         + (f", {nfused} cases through the fused layer+norm kernels" if args.fused else ""))
     if out:
         out.close()
     return 1 if fails else 0
