@@ -556,6 +556,7 @@ def test_seeded_slice_of_the_randomised_parity_run():
     for _ in range(40):
         case = fuzz_parity.draw_case(rng)
         bad, _ill_conditioned = fuzz_parity.run_case(case, mrng)
+        bad += fuzz_parity.run_fused(case) or []   # layer+LayerNorm / layer+max-abs kernels
         if bad:
             failures.append((case, bad))
     assert not failures, failures
