@@ -156,3 +156,19 @@ def test_block_pieces_match_the_torch_formulation(b, l, d, k, bias):
     out2 = run(True, (both, w, bs, nw))
     out2.backward(gy)
     assert torch.equal(out2, out)
+
+
+def test_seeded_slice_of_the_randomised_scan_run():
+    """30 cases of tests/fuzz_scan.py's distribution (batch, length, channels, states around the
+    scan kernels' variant boundaries) against the fp64 oracle."""
+    import random
+
+    import fuzz_scan
+    rng = random.Random(20261111)
+    failures = []
+    for _ in range(30):
+        case = fuzz_scan.draw_case(rng)
+        bad, _ill_conditioned = fuzz_scan.run_case(case)
+        if bad:
+            failures.append((case, bad))
+    assert not failures, failures
