@@ -75,3 +75,42 @@ def test_noalloc_forward_rejects_oversized_shapes_and_prepacked():
     assert rc == 0 and float(y.abs().max()) == 0.0
     rc, _ = _call_noalloc(lib, PF, x, w_t, spec, _lib.FWD_FP16X2 | _lib.WS_PREPACKED)
     assert rc == -5
+
+
+def test_noalloc_forward_on_a_random_sequence_of_shapes():
+    """60 calls in a row on randomly drawn layers and batch sizes (automatic method; the shared
+    scratch array keeps each call's pieces until the next overwrites them): the same bits as
+    pp_forward_ws_f32 every time, or the size refusal exactly when the workspace query says the
+    shape needs more than the array holds."""
+    import random
+
+    from language_interpolation_amd import _lib
+    from language_interpolation_amd import functional as PF
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    rng = random.Random(77)
+    ran = refused = 0
+    for _ in range(60):
+        disc = rng.random() < 0.4
+        n = rng.choice([1, 2, 3, 4, 5, 8]) if disc else rng.choice([2, 3, 4, 5, 8])
+        S = rng.choice([1, 2, 2, 2, 4, 16, 128])
+        I, O = rng.choice([16, 33, 64, 100, 250, 256, 400]), rng.choice([16, 40, 96, 128, 250, 300])
+        B = rng.choice([1, 100, 383, 384, 1000, 2049, 4096, 8200])
+        x, w, _ = make_inputs(B, I, O, n, S, disc, rng.choice(["normal", "uniform", "edges"]),
+                              seed=rng.randrange(1 << 20))
+        xd = x.cuda()
+        w_t = w.cuda().permute(1, 2, 0).contiguous()
+        spec = PF.make_spec(n, S, disc, in_features=I)
+        need = lib.pp_forward_workspace_bytes(B, I, O, n, S, int(disc), 2.0, _lib.METHOD_AUTO)
+        rc1, y1 = _call_noalloc(lib, PF, xd, w_t, spec, _lib.METHOD_AUTO)
+        rc2, y2 = _call_ws(lib, PF, xd, w_t, spec, _lib.METHOD_AUTO)
+        torch.cuda.synchronize()
+        assert rc2 == 0
+        if need > _lib.NOALLOC_SCRATCH_BYTES:
+            assert rc1 == -7, (B, I, O, n, S, disc, need)
+            refused += 1
+        else:
+            assert rc1 == 0, (B, I, O, n, S, disc, need)
+            assert torch.equal(y1, y2), (B, I, O, n, S, disc)
+            ran += 1
+    assert ran >= 40, (ran, refused)
