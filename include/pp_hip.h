@@ -23,7 +23,8 @@
  *     nothing and keeps no state between calls (safe from any host thread --
  *     autograd calls backward from its own engine thread; the only runtime
  *     state touched is hipFuncSetAttribute on the launching device, set on
- *     every call that needs it).
+ *     every call that needs it).  One exception, stated at its declaration:
+ *     pp_forward_noalloc_f32 keeps the per-device address of its scratch array.
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
  *     stream-ordered; no call synchronises the device.
  *   - B rows (samples), I in_features, O out_features, n nodes per segment,
@@ -135,11 +136,15 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
  * with the scratch taken from a fixed array inside the library (PP_NOALLOC_SCRATCH_BYTES per
  * GPU the library runs on, held until the process ends).  It has no counterpart in the
  * reference.  Same arguments and results as pp_forward_f32 / pp_forward_ws_f32 (bit-identical
- * to the latter); PP_METHOD_AUTO may pick the workspace methods.  Shapes whose method needs
- * more scratch than that return PP_ERR_NOALLOC_SIZE (pp_forward_workspace_bytes tells; a method
- * without scratch, e.g. PP_FWD_GATHER, always fits).  Allocates nothing, frees nothing.  Every
- * call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
- * threads) race -- serialise them or use pp_forward_ws_f32. */
+ * to the latter); PP_METHOD_AUTO may pick the workspace methods and, where the one it would pick
+ * needs more scratch than that, runs what pp_forward_f32 runs for the shape (no scratch).  An
+ * explicitly requested method that needs more returns PP_ERR_NOALLOC_SIZE
+ * (pp_forward_workspace_bytes tells; a method without scratch, e.g. PP_FWD_GATHER, always
+ * fits).  Allocates nothing, frees nothing.  State: the first call on a device looks up that
+ * device's copy of the array (hipGetSymbolAddress, under a mutex) and keeps the address -- make
+ * that first call outside stream capture; later calls are capture-safe.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race --
+ * serialise them or use pp_forward_ws_f32. */
 #define PP_NOALLOC_SCRATCH_BYTES (8u << 20)
 int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* seg_out, int B, int I,
                            int O, int n, int S, int discontinuous, float length, const float* nodes,
@@ -340,7 +345,8 @@ int pp_rms_norm_bwd_f32(const float* x, const float* weight, const float* rstd, 
  * the yaml files under /root/reference/config/optimizer, built at networks.py:183-190 from
  * lion_pytorch.Lion and high-order-layers-torch's SparseLion) for `count` <= PP_OPT_MAX_TENSORS
  * parameters in one launch:  u = sign(b1*m + (1-b1)*g);  p = p*(1 - lr*wd) - lr*u;
- * m = b2*m + (1-b2)*g;  sparse != 0: entries with g == 0 keep p (up to the decay) and m.
+ * m = b2*m + (1-b2)*g;  sparse != 0: entries with g == 0 keep p (not decayed either) and m
+ * (the upstream SparseLion is absent from /root/reference: parity unpinned).
  * p / g / m: device pointers to `numel[t]` floats each, same element order (storage order of the
  * parameter), updated in place.  Host arrays of `count` entries. */
 #define PP_OPT_MAX_TENSORS 32

@@ -1,6 +1,8 @@
 // C ABI of libpphip.so (declared in include/pp_hip.h): argument validation,
 // node table construction and method dispatch.  No allocation, no
-// synchronisation, no global state.
+// synchronisation.  The only state kept between calls belongs to the allocation-free entry
+// point (pp_forward_noalloc_f32): the per-device address of its scratch array, looked up once
+// per device under a mutex; every other entry point is stateless.
 #include <cmath>
 #include <cstdint>
 #include <mutex>
@@ -276,8 +278,14 @@ int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* 
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
   if (rc != PP_OK) return rc;
-  const size_t need = pp_forward_workspace_bytes(B, I, O, n, S, discontinuous, length, method);
-  if (need > (size_t)PP_NOALLOC_SCRATCH_BYTES) return PP_ERR_NOALLOC_SIZE;
+  size_t need = pp_forward_workspace_bytes(B, I, O, n, S, discontinuous, length, method);
+  if (need > (size_t)PP_NOALLOC_SCRATCH_BYTES) {
+    // an explicitly requested method is refused; the automatic choice falls back to what
+    // pp_forward_f32 would run for the shape (a method without scratch), which always fits
+    if (method != PP_METHOD_AUTO) return PP_ERR_NOALLOC_SIZE;
+    method = fwd_auto(sh, false);
+    need = 0;
+  }
   void* ptr = nullptr;
   if (need) {
     hipError_t e = scratch_on_current_device(&ptr);

@@ -360,10 +360,7 @@ __device__ __forceinline__ void lion_one(float& p, float g, float& m, float lr, 
   const float c = m * b1 + g * (1.0f - b1);
   float u = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
   float nm = m * b2 + g * (1.0f - b2);
-  if (sparse && g == 0.0f) {
-    u = 0.0f;
-    nm = m;
-  }
+  if (sparse && g == 0.0f) return;  // an entry no sample touched keeps value (no decay) and momentum
   p = p * decay - lr * u;
   m = nm;
 }

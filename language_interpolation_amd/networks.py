@@ -77,6 +77,7 @@ class HighOrderMLP(nn.Module):
         # LazyLayerNormLastDim (or MaxAbsNormalizationLast) runs as one kernel where the layer
         # has the fused epilogue
         mods = list(self.model)
+        PF._prepacked.clear()
         if x.is_cuda and x.dim() == 2:
             # the weights of all matrix-core layers are pre-split for this step in two launches
             PF.prepack_layers([m for m in mods if hasattr(m, "forward_layer_norm")], x.shape[0])
@@ -99,6 +100,10 @@ class HighOrderMLP(nn.Module):
                     continue
             x = m(x)
             i += 1
+        # the pre-split buffers belong to this step only (each layer's autograd node holds its
+        # own reference for the backward): a later call of self.model / a sub-layer must not find
+        # them after an optimizer that writes the weights through raw pointers or .data
+        PF._prepacked.clear()
         return x
 
 

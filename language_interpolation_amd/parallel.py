@@ -155,3 +155,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
             tmp = p.data.contiguous()
             dist.broadcast(tmp, src=src, group=process_group)
             p.data.copy_(tmp)
+    # writes through .data do not bump the parameters' version counters, which key the
+    # pre-split weight buffers of the step in flight: drop them
+    from . import functional as PF
+    PF._prepacked.clear()

@@ -235,6 +235,10 @@ class Lion(torch.optim.Optimizer):
                     (ctypes.c_long * cnt)(*[p.numel() for p, _, _ in part]),
                     lr, b1, b2, wd, int(self.sparse), _stream(part[0][0].device))
             _lib.check(rc, "pp_lion_step_f32")
+            # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and the
+            # pre-split weight cache (functional._prepacked, keyed by version) that p changed
+            for p, _, _ in part:
+                torch._C._increment_version(p)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -260,7 +264,10 @@ class Lion(torch.optim.Optimizer):
                     update = update * touched
                     new_m = torch.where(touched, new_m, m)
                 if wd:
-                    p.mul_(1 - lr * wd)
+                    if self.sparse:  # ... and are not decayed either
+                        p.copy_(torch.where(touched, p * (1 - lr * wd), p))
+                    else:
+                        p.mul_(1 - lr * wd)
                 p.add_(update, alpha=-lr)
                 m.copy_(new_m)
             if fused:

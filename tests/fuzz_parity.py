@@ -172,11 +172,16 @@ def run_case(case, rng=None):
 
 
 def run_fused(case):
-    """Failure strings for the layer+normalisation kernels (LayerNorm and max-abs epilogues) on
-    one case: forward and all gradients of the fused autograd function against the same two
-    modules run one after the other on the GPU (whose layer the main leg holds to the oracle),
-    and the forward against the fp64 oracle.  Skipped (None) where neither fusion applies or
-    the rows are too short for a meaningful variance."""
+    """(failures, ill_conditioned) for the layer+normalisation kernels (LayerNorm and max-abs
+    epilogues) on one case, or None where neither fusion applies or the rows are too short for
+    a meaningful variance.  Forward: fused against the two modules run one after the other and
+    against the fp64 oracle.  Gradients: the fused function's AND the two modules' against the
+    fp64 oracle of the layer+norm pair (oracle layer, oracle norm, torch autograd); a gradient
+    beyond the bar counts as ill-conditioned only by the tests every other leg uses -- its
+    error within the bar of the largest sum of |terms| behind one element, the terms taken with
+    the oracle's gradient at the layer's output (a one-input layer under a normalisation: every
+    output moves together, gx is what is left of a cancellation), or the reference formulation
+    of the pair evaluated in fp32 no more than twice as close to the fp64 result."""
     import torch
     from pp_testlib import TOL, make_inputs, rel_err
     from oracle import pp_oracle as po
@@ -189,7 +194,7 @@ def run_fused(case):
     x, w, gy = make_inputs(B, I, O, n, S, disc, dist=dist, seed=seed)
     spec = PF.make_spec(n, S, disc)
     wd0 = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1)
-    bad, ran = [], False
+    bad, soft, ran = [], [], False
     for name, fusable, fused, plain, oracle_norm in (
             ("layer_norm", PF.layer_norm_fusable, lambda a, b: PF.piecewise_poly_layer_norm(a, b, spec, 1e-5),
              lambda a, b: PF.layer_norm_last(PF.piecewise_poly(a, b, spec), 1e-5),
@@ -207,24 +212,59 @@ def run_fused(case):
             y = fn(xd, wd)
             y.backward(gy.cuda())
             res.append((y.detach().cpu(), xd.grad.cpu(), wd.grad.cpu()))
-        for key, a, b, bar in zip(("y", "gx", "gw"), res[0], res[1], (5e-6, 5e-5, 5e-5)):
-            if key == "gx" and a.numel() < 8:
-                # a gradient of a few elements through a normalisation is what is left of a
-                # cancellation (one input: every normalised output moves together): not compared
-                continue
-            if not torch.isfinite(a).all():
-                bad.append(f"{name}: {key} not finite")
-            elif b.abs().max() > 0 and not rel_err(a, b) <= bar:
-                bad.append(f"{name}: {key} fused vs two modules {rel_err(a, b):.3e}")
-        yo = oracle_norm(po.piecewise_forward_f64(x.float(), w.double(), n, S, disc))
+        # the fp64 oracle of the pair, with the gradient at the layer's output kept
+        x32 = x.detach().float().clone().requires_grad_(True)
+        w64 = w.detach().double().clone().requires_grad_(True)
+        raw = po.piecewise_forward_f64(x32, w64, n, S, disc)
+        raw.retain_grad()
+        yo = oracle_norm(raw)
+        yo.backward(gy.double())
+        ref = {"gx": x32.grad if x32.grad is not None else torch.zeros_like(x32), "gw": w64.grad}
+        raw, yo = raw.detach(), yo.detach()
+        scache = {}
+
+        def sums():
+            if not scache:
+                scache.update(abs_sums(x, w, raw.grad, n, S, disc))
+            return scache
+
+        c32 = {}
+
+        def ref32():  # the reference formulation of the pair evaluated in fp32
+            if not c32:
+                xa = x.detach().float().clone().requires_grad_(True)
+                wa = w.detach().float().clone().requires_grad_(True)
+                oracle_norm(po.piecewise_forward(xa, wa, n, S, disc)).backward(gy.float())
+                c32.update(gx=xa.grad if xa.grad is not None else torch.zeros_like(xa), gw=wa.grad)
+            return c32
+
+        if not rel_err(res[0][0], res[1][0]) <= 5e-6:
+            bad.append(f"{name}: y fused vs two modules {rel_err(res[0][0], res[1][0]):.3e}")
+        for which, r in zip(("fused", "two modules"), res):
+            for key, got in (("gx", r[1]), ("gw", r[2])):
+                if not torch.isfinite(got).all():
+                    bad.append(f"{name}: {key} ({which}) not finite")
+                    continue
+                rmax = ref[key].abs().max().item()
+                if rmax == 0:
+                    if got.abs().max() != 0:
+                        bad.append(f"{name}: {key} ({which}) non-zero where the oracle is zero")
+                    continue
+                e = rel_err(got, ref[key])
+                if e <= 5e-5:
+                    continue
+                cancel = rmax / max(sums()[key], 1e-300)
+                e32 = rel_err(ref32()[key], ref[key])
+                msg = (f"{name}: {key} ({which}) vs the fp64 oracle of the pair {e:.3e} "
+                       f"(fp32 reference: {e32:.3e}; max|ref| / max sum|terms| = {cancel:.2e})")
+                (soft if (e <= 2 * e32 or e * cancel <= 5e-5) else bad).append(msg)
         # (rows whose layer output is almost constant, or almost zero, amplify the layer's own
         # rounding: the bar is the network test's 5 * TOL, rows with a tiny spread left out)
-        raw = po.piecewise_forward_f64(x.float(), w.double(), n, S, disc)
         spread = raw.std(dim=1) if name == "layer_norm" else raw.abs().amax(dim=1)
         keep = spread > 1e-2 * spread.median().clamp_min(1e-30)
         if keep.any() and not rel_err(res[0][0][keep], yo[keep]) <= 5 * TOL:
             bad.append(f"{name}: y vs oracle {rel_err(res[0][0][keep], yo[keep]):.3e}")
-    return bad if ran else None
+    return (bad, soft) if ran else None
 
 
 def main():
@@ -256,7 +296,9 @@ def main():
         if args.fused:
             fb = run_fused(case)
             nfused += fb is not None
-            bad += fb or []
+            if fb is not None:
+                bad += fb[0]
+                soft += fb[1]
         done += 1
         if bad:
             fails += 1

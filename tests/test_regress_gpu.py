@@ -486,9 +486,47 @@ def test_multi_layer_weight_pack_equals_per_layer_pack():
                           normalization=L.LazyLayerNormLastDim, device="cuda")
     x = torch.rand(512, 16, device="cuda") * 2 - 1
     y1 = net(x)
-    PF._prepacked.clear()
+    assert not PF._prepacked  # the step's buffers do not outlive HighOrderMLP.forward
     y2 = net.model(x)
     assert torch.allclose(y1, y2, rtol=0, atol=2e-6 * y2.abs().max().item())
+
+
+def test_no_stale_presplit_weights_after_a_fused_optimizer_step():
+    """The fused Lion / SparseLion kernel writes the weights through raw pointers: the next
+    forward -- through the network, its Sequential, or one sub-layer -- must see the new weights
+    (version counters bumped, the step's pre-split buffers dropped), and autograd's saved-tensor
+    check must notice the in-place update."""
+    import language_interpolation_amd as L
+    from language_interpolation_amd import networks as NW
+    from language_interpolation_amd.train import Lion
+    PF = _pf()
+    torch.manual_seed(5)
+    net = NW.HighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=32, hidden_layers=2,
+                          hidden_width=64, in_segments=8, out_segments=2, hidden_segments=2,
+                          normalization=L.LazyLayerNormLastDim, device="cuda")
+    opt = Lion(net.parameters(), lr=1e-2, sparse=True)
+    x = torch.rand(512, 16, device="cuda") * 2 - 1
+    versions = [p._version for p in net.parameters()]
+    y0 = net(x)
+    y0.square().mean().backward()
+    PF.prepack_layers([m for m in net.model if hasattr(m, "forward_layer_norm")], 512)  # leftovers
+    opt.step()
+    assert all(p._version > v for p, v in zip(net.parameters(), versions))
+    with torch.no_grad():
+        y_seq = net.model(x)  # finds no usable buffer: versions moved
+        h0 = net.model[0](x)
+        PF._prepacked.clear()
+        y_ref = net.model(x)
+        h0_ref = net.model[0](x)
+        y_net = net(x)
+    assert torch.equal(y_seq, y_ref) and torch.equal(h0, h0_ref)
+    assert torch.allclose(y_net, y_ref, rtol=0, atol=2e-6 * y_ref.abs().max().item())
+    assert not torch.equal(y_ref, y0.detach())  # the step did move the weights
+    # a backward across an optimizer step is refused instead of using changed weights
+    y1 = net(x)
+    opt.step()
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y1.sum().backward()
 
 
 # batch sizes on both sides of every dispatch threshold of the small-batch work: one row per
@@ -556,7 +594,7 @@ def test_seeded_slice_of_the_randomised_parity_run():
     for _ in range(40):
         case = fuzz_parity.draw_case(rng)
         bad, _ill_conditioned = fuzz_parity.run_case(case, mrng)
-        bad += fuzz_parity.run_fused(case) or []   # layer+LayerNorm / layer+max-abs kernels
+        bad += (fuzz_parity.run_fused(case) or ([], []))[0]   # layer+LayerNorm / layer+max-abs kernels
         if bad:
             failures.append((case, bad))
     assert not failures, failures

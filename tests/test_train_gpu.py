@@ -190,10 +190,14 @@ def test_fused_lion_step_matches_the_torch_rule(sparse):
             g[torch.rand(pc.shape) < 0.3] = 0.0
             pc.grad = g.clone()
             pg.grad = torch.empty_like(pg).copy_(g)     # same strides as the parameter
+        before = [pg.detach().cpu().clone() for pg in gpu_p]
         opt_c.step()
         opt_g.step()
-        for pc, pg in zip(cpu_p, gpu_p):
+        for pc, pg, b4 in zip(cpu_p, gpu_p, before):
             assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=0, atol=1e-6), step
+            if sparse:  # untouched entries keep their bits: no update, no weight decay
+                untouched = pc.grad == 0
+                assert torch.equal(pg.detach().cpu()[untouched], b4[untouched]), step
             mc, mg = opt_c.state[pc]["exp_avg"], opt_g.state[pg]["exp_avg"]
             assert torch.allclose(mg.cpu(), mc, rtol=1e-6, atol=1e-7), step
 

@@ -80,8 +80,9 @@ def test_noalloc_forward_rejects_oversized_shapes_and_prepacked():
 def test_noalloc_forward_on_a_random_sequence_of_shapes():
     """60 calls in a row on randomly drawn layers and batch sizes (automatic method; the shared
     scratch array keeps each call's pieces until the next overwrites them): the same bits as
-    pp_forward_ws_f32 every time, or the size refusal exactly when the workspace query says the
-    shape needs more than the array holds."""
+    pp_forward_ws_f32 every time; where the workspace query says the automatic method needs more
+    than the array holds, the bits of pp_forward_f32 (the automatic choice without scratch) and
+    the size refusal for the scratch method asked for by name."""
     import random
 
     from language_interpolation_amd import _lib
@@ -107,10 +108,57 @@ def test_noalloc_forward_on_a_random_sequence_of_shapes():
         torch.cuda.synchronize()
         assert rc2 == 0
         if need > _lib.NOALLOC_SCRATCH_BYTES:
-            assert rc1 == -7, (B, I, O, n, S, disc, need)
+            # the automatic choice falls back to the method pp_forward_f32 runs (no scratch);
+            # the method that needs the scratch, asked for by name, is refused
+            assert rc1 == 0, (B, I, O, n, S, disc, need)
+            y3 = torch.full_like(y1, float("nan"))
+            rc3 = lib.pp_forward_f32(
+                PF._ptr(xd), PF._ptr(w_t), PF._ptr(y3), PF._ptr(None), B, I, O, n, S, int(disc),
+                spec.length, spec.node_array(), spec.out_scale, _lib.METHOD_AUTO,
+                PF._stream(xd.device))
+            rc4, _ = _call_noalloc(lib, PF, xd, w_t, spec, _lib.FWD_FP16X2)
+            torch.cuda.synchronize()
+            assert rc3 == 0 and torch.equal(y1, y3), (B, I, O, n, S, disc)
+            assert rc4 == -7, (B, I, O, n, S, disc, need)
             refused += 1
         else:
             assert rc1 == 0, (B, I, O, n, S, disc, need)
             assert torch.equal(y1, y2), (B, I, O, n, S, disc)
             ran += 1
     assert ran >= 40, (ran, refused)
+
+
+def test_noalloc_forward_under_stream_capture():
+    """The entry point inside a HIP graph capture (the callers it exists for): after one call
+    outside capture -- the first call on a device looks up the scratch address -- a captured call
+    replays to the same bits as pp_forward_ws_f32, twice, the second replay on new inputs."""
+    from language_interpolation_amd import _lib
+    from language_interpolation_amd import functional as PF
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    B, I, O, n, S, disc = 2048, 250, 250, 3, 2, False
+    x, w, _ = make_inputs(B, I, O, n, S, disc, "normal", seed=91)
+    xd = x.cuda()
+    w_t = w.cuda().permute(1, 2, 0).contiguous()
+    spec = PF.make_spec(n, S, disc, in_features=I)
+    rc, _ = _call_noalloc(lib, PF, xd, w_t, spec, _lib.METHOD_AUTO)   # resolves the address
+    assert rc == 0
+    y = torch.full((B, O), float("nan"), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = lib.pp_forward_noalloc_f32(
+                PF._ptr(xd), PF._ptr(w_t), PF._ptr(y), PF._ptr(None), B, I, O, n, S, int(disc),
+                spec.length, spec.node_array(), spec.out_scale, _lib.METHOD_AUTO,
+                PF._stream(xd.device))
+    assert rc == 0
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(2):
+        if rep:
+            xd.copy_(make_inputs(B, I, O, n, S, disc, "uniform", seed=92)[0])
+        graph.replay()
+        rc2, y2 = _call_ws(lib, PF, xd, w_t, spec, _lib.METHOD_AUTO)
+        torch.cuda.synchronize()
+        assert rc2 == 0 and torch.equal(y, y2), rep
