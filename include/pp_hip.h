@@ -77,6 +77,13 @@ enum {
   PP_FWD_SLAB = 5,    /* many segments, few inputs, large batch (the character-grid input layers):
                          the weight slab of one input staged in LDS by LDS-DMA, rows gathered from
                          there; PP_METHOD_AUTO picks it where it applies, else PP_ERR_METHOD */
+  PP_FWD_TILE = 6,    /* many segments, large batch (cfg3 hidden, cfg4 input): a workgroup keeps the
+                         accumulators of a tall tile of rows x 64 outs in registers, the slab of the
+                         current input streams through LDS by LDS-DMA, one ds_read_b128 serves four
+                         rows (lanes rotate over the rows by DPP); the inputs are split over
+                         workgroups when the output is too small to fill the chip -- partial outputs
+                         in the workspace (pp_forward_workspace_bytes), summed in a fixed order.
+                         O % 4 == 0, n <= 4, K <= 320; bitwise reproducible */
   PP_BWD_W_ATOMIC = 1, /* global float atomics into gw */
   PP_BWD_W_SORT = 2,   /* counting sort by (input, segment) + segmented reduce; float atomics only
                           for buckets shared between segments (continuous layers) or spanning
@@ -225,6 +232,11 @@ int pp_transpose_wt_f32(const float* w_t, float* w, int O, int I, int K, void* s
  * for this shape (the kernel PP_METHOD_AUTO would pick for the layer alone has it), else 0. */
 int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
                                     float length);
+/* ... 3: the row-tile kernel (PP_FWD_TILE) with the normalisation in the kernel that sums its
+ * partial outputs; the caller then passes pp_forward_layer_norm_workspace_bytes() of scratch as
+ * `packed` / `packed_bytes` (contents undefined on entry and exit).  0 for the other modes. */
+size_t pp_forward_layer_norm_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                             float length);
 int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float* rstd,
                               void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
                               int discontinuous, float length, const float* nodes, float out_scale,

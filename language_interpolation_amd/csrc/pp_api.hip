@@ -96,6 +96,10 @@ bool dense_preferred(const PPShape& sh) {
 // The forward stays on the gather kernel a little longer (cfg2 hidden, 250 -> 250 at 256 rows:
 // 14 us against 20 for the fp16x2 kernel's 8 workgroups; level at ~400 rows, 25 vs 21 at 512).
 bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 384; }
+
+// The row-tile forward where it is the faster kernel and its scratch (per-row records, partial
+// outputs) is at hand.
+bool tile_fwd(const PPShape& sh, bool have_ws) { return pp_tile_fwd_preferred(sh) && have_ws; }
 bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
 
 }  // namespace
@@ -128,7 +132,8 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
   const bool dense = dense_preferred(sh);
   switch (pass) {
     case 0: return matrix_core_fwd(sh) ? (pp_bf3_supported(sh) ? PP_FWD_FP16X2 : PP_FWD_DENSE)
-                                       : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
+                   : tile_fwd(sh, true) ? PP_FWD_TILE
+                                        : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
     case 1: return matrix_core_bwd_x(sh)
                        ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
                        : PP_BWD_X_GATHER;
@@ -205,7 +210,10 @@ int pp_pack_weights_multi_f32(int count, const float* const* w_t, void* const* p
 }
 
 static int fwd_auto(const PPShape& sh, bool have_ws) {
-  if (!matrix_core_fwd(sh)) return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
+  if (!matrix_core_fwd(sh)) {
+    if (tile_fwd(sh, have_ws)) return PP_FWD_TILE;
+    return pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER;
+  }
   if (have_ws && pp_bf3_supported(sh)) return PP_FWD_FP16X2;
   return PP_FWD_DENSE;
 }
@@ -217,6 +225,7 @@ size_t pp_forward_workspace_bytes(int B, int I, int O, int n, int S, int discont
   if (method == PP_METHOD_AUTO) method = fwd_auto(sh, true);
   if ((method == PP_FWD_BF16X3 || method == PP_FWD_FP16X2) && pp_bf3_supported(sh))
     return pp_bf3_fwd_workspace_bytes(sh);
+  if (method == PP_FWD_TILE && pp_tile_fwd_supported(sh)) return pp_tile_fwd_workspace_bytes(sh, false);
   return 0;
 }
 
@@ -242,9 +251,17 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
     method = fwd_auto(sh, workspace != nullptr);
     if (method == PP_FWD_FP16X2 && workspace_bytes < pp_bf3_fwd_workspace_bytes(sh))
       method = PP_FWD_DENSE;
+    if (method == PP_FWD_TILE && workspace_bytes < pp_tile_fwd_workspace_bytes(sh, false))
+      method = fwd_auto(sh, false);
   }
   hipStream_t st = (hipStream_t)stream;
   if (method == PP_FWD_GATHER) return hip_rc(pp_launch_fwd_gather(x, w_t, y, seg_out, sh, tab, st));
+  if (method == PP_FWD_TILE) {
+    if (!pp_tile_fwd_supported(sh)) return PP_ERR_METHOD;
+    const size_t need = pp_tile_fwd_workspace_bytes(sh, false);
+    if (need && (!workspace || workspace_bytes < need)) return PP_ERR_WORKSPACE;
+    return hip_rc(pp_launch_fwd_tile(x, w_t, y, seg_out, workspace, nullptr, 0.0f, sh, tab, st));
+  }
   if (method == PP_FWD_SLAB) {
     if (!pp_slab_fwd_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_fwd_slab(x, w_t, y, seg_out, sh, tab, st));
@@ -455,6 +472,15 @@ int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float*
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
   if (rc != PP_OK) return rc;
+  if (packed && !matrix_core_fwd(sh) && tile_fwd(sh, true) && sh.O <= 1024) {
+    // mode 3: `packed` is the row-tile kernel's scratch; the kernel that sums the partial
+    // outputs normalises the rows
+    if (packed_bytes < pp_tile_fwd_workspace_bytes(sh, true)) return PP_ERR_WORKSPACE;
+    BasisTab ttab;
+    make_basis(ttab, n, length, nodes);
+    return hip_rc(pp_launch_fwd_tile(x, w_t, y, nullptr, packed, rstd, eps, sh, ttab,
+                                     (hipStream_t)stream));
+  }
   if (!packed) {  // gather path: the wave that sums a row normalises it
     if (!pp_gather_ln_supported(sh)) return PP_ERR_METHOD;
     BasisTab gtab;
@@ -475,10 +501,19 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && matrix_core_fwd(sh))
     return 1;
+  if (!matrix_core_fwd(sh) && tile_fwd(sh, true) && sh.O <= 1024) return 3;
   // layers the gather kernels serve (many segments, first layers, lengths off the matrix-core
   // path): fused there too
   if (!matrix_core_fwd(sh) && pp_gather_ln_supported(sh)) return 2;
   return 0;
+}
+
+size_t pp_forward_layer_norm_workspace_bytes(int B, int I, int O, int n, int S, int discontinuous,
+                                             float length) {
+  if (pp_forward_layer_norm_supported(B, I, O, n, S, discontinuous, length) != 3) return 0;
+  PPShape sh;
+  make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f);
+  return pp_tile_fwd_workspace_bytes(sh, true);
 }
 
 int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,

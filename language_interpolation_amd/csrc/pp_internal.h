@@ -41,6 +41,14 @@ bool pp_slab_fwd_preferred(const PPShape& sh);  // ... and measured faster than 
 hipError_t pp_launch_fwd_slab(const float* x, const float* wt, float* y, int32_t* seg,
                               const PPShape& sh, const BasisTab& tab, hipStream_t st);
 
+// ---- row-tile path: accumulators of a tall row tile in registers, slab in LDS (pp_tile.hip) ----
+bool pp_tile_fwd_supported(const PPShape& sh);
+bool pp_tile_fwd_preferred(const PPShape& sh);
+size_t pp_tile_fwd_workspace_bytes(const PPShape& sh, bool with_norm);
+hipError_t pp_launch_fwd_tile(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
+                              float* rstd, float ln_eps, const PPShape& sh, const BasisTab& tab,
+                              hipStream_t st);
+
 // ---- sort + segmented reduce path (pp_sort.hip) ----
 size_t pp_sort_workspace_bytes(const PPShape& sh);
 bool pp_sort_supported(const PPShape& sh);

@@ -341,10 +341,15 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         if mode == 0 or (mode == 1 and packed is None):
             raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
         fwd_packed = packed if mode == 1 else None
+        if mode == 3:  # row-tile kernel: its scratch goes in through the same argument
+            nbytes = lib.pp_forward_layer_norm_workspace_bytes(
+                B, I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length)
+            fwd_packed = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)
         rstd = torch.empty(B, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            # mode 2: no packed weights -> the gather kernel with whole rows per wave
+            # mode 2: no packed weights -> the gather kernel with whole rows per wave;
+            # mode 3: the row-tile kernel, normalisation in the kernel that sums its partials
             rc = lib.pp_forward_layer_norm_f32(
                 _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(fwd_packed),
                 fwd_packed.numel() if fwd_packed is not None else 0, B, I, O,

@@ -23,6 +23,7 @@ LAYERS = {
     "cfg2_out": (False, 3, 250, 128, 2, "normal", False),
     "cfg3_hidden": (True, 1, 200, 200, 150, "normal", False),
     "cfg3_quirk": (True, 2, 200, 200, 150, "normal", False),
+    "cfg3_out": (True, 1, 200, 128, 150, "normal", False),
     "cfg4_input": (True, 2, 16, 1000, 128, "char", True),
     "cfg5_inproj2": (False, 3, 256, 256, 2, "normal", False),
 }
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[1024, 16384])
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--fwd-only", action="store_true")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -65,7 +67,7 @@ def main():
             w_t = ((torch.rand(I, K, O, generator=gen) * 2 - 1) / I).to(dev)
             gy = (torch.randn(B, O, generator=gen) / O).to(dev)
             rows = []
-            for m in ("gather", "slab", "dense", "bf16x3", "fp16x2"):
+            for m in ("gather", "slab", "tile", "dense", "bf16x3", "fp16x2"):
                 spec = PF.make_spec(n, S, disc, fwd_method=m)
                 try:
                     t = time_fn(lambda: PF.forward_raw(x, w_t, spec), args.iters)
@@ -83,7 +85,7 @@ def main():
                     t = time_fn(lambda: PF.piecewise_poly_layer_norm(x, w_log, spec, 1e-5),
                                 args.iters)
                 rows.append((f"fwd+LN/{mode}", t, 4 * (B * I + B * O + W), 2 * B * I * O * n))
-            if not first:
+            if not first and not args.fwd_only:
                 for m in ("gather", "dense", "bf16x3", "fp16x2"):
                     spec = PF.make_spec(n, S, disc, bwd_x_method=m)
                     try:
@@ -92,7 +94,7 @@ def main():
                         continue
                     by = 4 * (2 * B * I + B * O + W)
                     rows.append((f"bwd_x/{m}", t, by, 2 * B * I * O * n))
-            for m in ("atomic", "sort", "regacc", "direct", "dense", "bf16x3", "fp16x2"):
+            for m in (() if args.fwd_only else ("atomic", "sort", "regacc", "direct", "dense", "bf16x3", "fp16x2")):
                 spec = PF.make_spec(n, S, disc, bwd_w_method=m)
                 try:
                     t = time_fn(lambda: PF.backward_weight_raw(x, gy, tuple(w_t.shape), spec),
