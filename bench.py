@@ -39,12 +39,32 @@ NET = dict(layer_type="continuous", n=3, n_in=2, n_hidden=3, n_out=3, in_width=1
            hidden_layers=3, hidden_width=250, in_segments=128, out_segments=2, hidden_segments=2)
 
 
+RAVEN_HIST = os.path.join(ROOT, "tests", "golden", "raven_byte_hist.json")
+
+
+def raven_char_probs():
+    """Byte probabilities of the reference's own training text (books/the_raven.txt: 2,822,602
+    ASCII characters, 90 distinct, 24 % spaces) -- SURVEY.md 8d's distribution for the
+    character-grid input layers.  A committed histogram (tests/golden/make_raven_hist.py), not
+    the book: /root/reference does not exist on the GPU box."""
+    with open(RAVEN_HIST) as f:
+        counts = torch.tensor(json.load(f)["counts"], dtype=torch.float64)
+    return counts / counts.sum()
+
+
 def char_batch(B, I, gen):
-    """x = (c - 63.5)/64 with c distributed like ASCII text (single_text_dataset.py:15-16)."""
-    c = torch.randint(32, 127, (B, I), generator=gen)
-    c[torch.rand(B, I, generator=gen) < 0.18] = 32
-    c[torch.rand(B, I, generator=gen) < 0.02] = 10
+    """x = (c - 63.5)/64 (single_text_dataset.py:15-16) with c drawn i.i.d. from the byte
+    histogram of the reference's text."""
+    c = torch.multinomial(raven_char_probs(), B * I, replacement=True, generator=gen).view(B, I)
     return (c.float() - 64 + 0.5) / 64
+
+
+def raven_like_text(nchar, seed):
+    """Bytes drawn i.i.d. from the same histogram (the train chars/s figure gathers its
+    character windows from this buffer on the device)."""
+    g = torch.Generator().manual_seed(seed)
+    c = torch.multinomial(raven_char_probs(), nchar, replacement=True, generator=g)
+    return bytes(c.to(torch.uint8).tolist())
 
 
 def time_kernel(fn, iters=20, warm=3):
@@ -231,9 +251,9 @@ def train_chars_per_s(net, dev, B, steps, world, reducer, graph, optimizer="spar
     kernel per step, train.Lion) or Adam.  One process: the step is replayed from a HIP graph
     (train.GraphedTrainStep); several: eager launches with the RCCL all-reduce of the
     gradients overlapping the backward."""
-    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, Lion, synthetic_text
+    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, Lion
 
-    data = CharWindows(synthetic_text(1 << 20, seed=7), 16, device=dev)
+    data = CharWindows(raven_like_text(1 << 20, seed=7), 16, device=dev)
     gen = torch.Generator(device=dev).manual_seed(11)
     module = _TrainModule(net)
     graph = graph and reducer is None
@@ -510,7 +530,8 @@ def main():
             "dtype": "f32",
             "arith": "fp32 in/out/accumulate; the segments=2 layers run fp16 MFMA on 2-way split "
                      "operands (~22 significant bits, 1e-5 parity bar), the rest plain fp32",
-            "data": "synthetic",
+            "data": "synthetic: characters drawn i.i.d. from the byte histogram of the reference's "
+                    "books/the_raven.txt (SURVEY 8d), random-init weights, gy ~ N(0,1)/O",
             "config": {
                 "workload": "BASELINE configs[1]: net=small width=250 n=3 hidden.layers=3 segments=2 "
                             "continuous; fwd+bwd of the 5 polynomial layers (+LayerNorm between), "

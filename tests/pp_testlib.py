@@ -1,6 +1,9 @@
 """Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
 from __future__ import annotations
 
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -9,11 +12,21 @@ from oracle import pp_oracle as po
 TOL = 1e-5  # north_star: fp32 outputs and gradients within 1e-5 relative of the reference
 
 
+RAVEN_HIST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raven_byte_hist.json")
+
+
+def raven_char_probs():
+    """128 byte probabilities of the reference's training text books/the_raven.txt (SURVEY 8d;
+    the counts are a committed fixture, tests/golden/make_raven_hist.py)."""
+    with open(RAVEN_HIST) as f:
+        counts = torch.tensor(json.load(f)["counts"], dtype=torch.float64)
+    return counts / counts.sum()
+
+
 def char_grid(B, I, gen):
-    """x = (c - 63.5)/64 with c drawn like ASCII text (single_text_dataset.py:15-16)."""
-    c = torch.randint(32, 127, (B, I), generator=gen)
-    c[torch.rand(B, I, generator=gen) < 0.18] = 32  # spaces dominate real text
-    c[torch.rand(B, I, generator=gen) < 0.02] = 10
+    """x = (c - 63.5)/64 with c drawn from the byte histogram of the reference's text
+    (single_text_dataset.py:15-16, :102-123): 90 distinct bytes, 24 % spaces."""
+    c = torch.multinomial(raven_char_probs(), B * I, replacement=True, generator=gen).view(B, I)
     return po.ascii_to_float(c)
 
 

@@ -59,9 +59,8 @@ def main():
         W = O * I * K
         for B in args.batch:
             if dist == "char":
-                c = torch.randint(32, 127, (B, I), generator=gen)
-                c[torch.rand(B, I, generator=gen) < 0.18] = 32
-                x = ((c.float() - 63.5) / 64).to(dev)
+                from bench import char_batch
+                x = char_batch(B, I, gen).to(dev)
             else:
                 x = torch.randn(B, I, generator=gen).to(dev)
             w_t = ((torch.rand(I, K, O, generator=gen) * 2 - 1) / I).to(dev)
