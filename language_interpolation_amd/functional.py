@@ -228,12 +228,30 @@ def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None):
     return gx
 
 
-def backward_weight_raw(x, gy, w_shape_t, spec: LayerSpec):
-    """gw_t[I,K,O] (kernel layout), dense."""
+# Gradient buffers assigned ahead of the backward (parallel.FlatGradBucket): storage pointer of a
+# layer's parameter -> the [I,K,O] tensor its weight gradient is written into (a slice of one
+# flat buffer that is all-reduced in place).  Empty unless a bucket registered itself.
+_grad_out = {}
+
+
+def _assigned_grad(w: torch.Tensor, shape_t):
+    """The pre-assigned gradient buffer of parameter w, if there is one and autograd will take
+    the returned tensor as w.grad (w.grad is None: an existing gradient is accumulated into,
+    which must not alias the tensor being added)."""
+    if not _grad_out or w.grad is not None:
+        return None
+    out = _grad_out.get(w.data_ptr())
+    if out is None or tuple(out.shape) != tuple(shape_t) or out.device != w.device:
+        return None
+    return out
+
+
+def backward_weight_raw(x, gy, w_shape_t, spec: LayerSpec, out=None):
+    """gw_t[I,K,O] (kernel layout), dense; written into `out` when given."""
     lib = _lib.load()
     B, I = x.shape
     I2, K, O = w_shape_t
-    gw_t = torch.empty(I2, K, O, device=x.device, dtype=torch.float32)
+    gw_t = out if out is not None else torch.empty(I2, K, O, device=x.device, dtype=torch.float32)
     if B == 0:
         return gw_t.zero_()
     method = _lib.BWD_W_METHODS[spec.bwd_w_method]
@@ -299,7 +317,8 @@ class PiecewisePolyFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = backward_input_raw(x, gy, w_t, spec, packed=ctx.packed)
         if ctx.needs_input_grad[1]:
-            gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec)
+            gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec,
+                                       out=_assigned_grad(w, w_t.shape))
             gw = gw_t.permute(2, 0, 1)  # logical [O,I,K]; same strides as the module's parameter
         return gx, gw, None
 
@@ -380,7 +399,8 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = backward_input_raw(x, g, w_t, spec, packed=ctx.packed)
         if ctx.needs_input_grad[1]:
-            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec).permute(2, 0, 1)
+            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
+                                     out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
         return gx, gw, None, None
 
 
@@ -445,7 +465,8 @@ class PiecewisePolyMaxAbsFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = backward_input_raw(x, g, w_t, spec)
         if ctx.needs_input_grad[1]:
-            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec).permute(2, 0, 1)
+            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
+                                     out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
         return gx, gw, None, None
 
 

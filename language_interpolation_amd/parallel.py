@@ -99,48 +99,127 @@ class GradAllReducer:
         self._handles.clear()
 
 
-class GraphedGradAllReduce:
-    """Gradient exchange for a step whose forward+backward is replayed from a HIP graph: the
-    gradients then live in the graph's static buffers, so after each replay they are summed
-    over the ranks through one flat bucket and scaled by 1/world, in place.  No hooks (nothing of
-    autograd runs at replay)."""
+class FlatGradBucket:
+    """All gradients of a replica as views of ONE flat buffer, so that the exchange is a single
+    in-place all-reduce of that buffer: no concatenation before it, no copy back after it.
+
+    * polynomial layers (permuted leaves on the GPU): the layer's backward writes its weight
+      gradient straight into the layer's slice (functional._grad_out) and autograd takes that
+      tensor as `p.grad` -- the bucket costs them nothing;
+    * every other parameter: `p.grad` is pre-set to its (zeroed) slice and autograd accumulates
+      into it in place.
+
+    Per step: `prepare()` before the forward/backward (also inside a HIP-graph capture: the
+    replay then reproduces the same in-place writes), `all_reduce()` after it.  `p.grad` keeps
+    the parameter's strides (the optimizer kernels walk p, g, m in storage order)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
-                 small_numel: int = 65536, average: bool = True):
+                 average: bool = True):
+        from . import functional as PF
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.small_numel = small_numel
         self.scale = (1.0 / self.world) if average else 1.0
-
-    def __call__(self) -> None:
-        if self.world <= 1:
-            return
-        # ONE bucket: every gradient's storage-order view copied into a flat buffer, one
-        # all-reduce, one scale, one multi-tensor copy back -- a collective per parameter
-        # costs its launch latency five times a step for these 0.6-2 MB tensors.  (small_numel
-        # is kept for the constructor's signature; everything shares the bucket.)
-        views = []
+        if not self.params:
+            raise ValueError("FlatGradBucket: no parameter requires a gradient")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views = []    # p.grad-shaped views (logical shape, the parameter's strides)
+        self.direct = []   # True: the layer's backward writes the slice itself
+        self._keys = []
+        self._slices = []
+        off = 0
         for p in self.params:
+            n = p.numel()
+            phys = _physical_view(p.data)
+            if not phys.is_contiguous():
+                raise ValueError("FlatGradBucket: parameter without a storage-order view")
+            sl = self.flat[off:off + n].view(phys.shape)
+            permuted = phys.shape != p.shape or phys.stride() != p.stride()
+            self.views.append(sl.permute(2, 0, 1) if permuted else sl)
+            self.direct.append(bool(permuted and p.is_cuda and p.dim() == 3))
+            self._slices.append(sl)
+            off += n
+        self._generic = [v for v, d in zip(self.views, self.direct) if not d]
+        self.register()
+
+    def register(self) -> None:
+        """Tell the layers' backward where their weight gradients go (undone by release())."""
+        from . import functional as PF
+        for p, sl, d in zip(self.params, self._slices, self.direct):
+            if d and p.data_ptr() not in self._keys:
+                PF._grad_out[p.data_ptr()] = sl
+                self._keys.append(p.data_ptr())
+
+    def prepare(self) -> None:
+        """Before the step's backward: slices that autograd accumulates into start at zero."""
+        if self._generic:
+            torch._foreach_zero_(self._generic)
+        for p, v, d in zip(self.params, self.views, self.direct):
+            p.grad = None if d else v
+
+    def collect(self) -> None:
+        """After the backward: every p.grad must BE its slice.  A gradient autograd produced
+        elsewhere (cloned instead of taken, a layer run through another path) is copied in."""
+        for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None:
-                continue
-            v = _physical_view(g)
-            if not v.is_contiguous():  # no storage-order view: reduce a copy, write it back
-                c = g.contiguous()
-                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
-                g.copy_(c.mul_(self.scale) if self.scale != 1.0 else c)
-                continue
-            views.append(v.reshape(-1))
-        if not views:
-            return
-        flat = torch.cat(views)
-        # plain stream-ordered collective: RCCL enqueues on its own stream and the current
-        # stream waits for it
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                v.zero_()
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                v.copy_(g)
+                p.grad = v
+
+    def all_reduce(self, async_op: bool = False):
+        """One collective over the whole bucket (sum, then 1/world), in place."""
+        if self.world <= 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            return work
         if self.scale != 1.0:
-            flat.mul_(self.scale)
-        torch._foreach_copy_(views, list(flat.split([v.numel() for v in views])))
+            self.flat.mul_(self.scale)
+        return None
+
+    def finish(self, work) -> None:
+        """Wait for an async all_reduce() and apply the 1/world scale."""
+        if work is not None:
+            work.wait()
+            if self.scale != 1.0:
+                self.flat.mul_(self.scale)
+
+    def release(self) -> None:
+        from . import functional as PF
+        for k in self._keys:
+            PF._grad_out.pop(k, None)
+        self._keys.clear()
+
+
+class GraphedGradAllReduce:
+    """Gradient exchange for a step whose forward+backward is replayed from a HIP graph: the
+    gradients live in the slices of a FlatGradBucket (the graph's static gradient buffers ARE the
+    bucket), so after each replay the exchange is one in-place all-reduce and one scale -- no
+    concatenation, no copy back.  No hooks (nothing of autograd runs at replay).
+
+        red = GraphedGradAllReduce(params)
+        def compute(): red.prepare(); loss(...).backward(); red.collect()    # captured once
+        ... graph.replay(); red()                                             # every step
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None,
+                 small_numel: int = 65536, average: bool = True):
+        self.bucket = FlatGradBucket(params, process_group, average)
+        self.world = self.bucket.world
+
+    def prepare(self) -> None:
+        self.bucket.prepare()
+
+    def collect(self) -> None:
+        self.bucket.collect()
+
+    def __call__(self) -> None:
+        self.bucket.all_reduce()
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None) -> None:

@@ -220,12 +220,13 @@ def run_fused(case):
         yo = oracle_norm(raw)
         yo.backward(gy.double())
         ref = {"gx": x32.grad if x32.grad is not None else torch.zeros_like(x32), "gw": w64.grad}
+        g_raw = raw.grad.detach()
         raw, yo = raw.detach(), yo.detach()
         scache = {}
 
         def sums():
             if not scache:
-                scache.update(abs_sums(x, w, raw.grad, n, S, disc))
+                scache.update(abs_sums(x, w, g_raw, n, S, disc))
             return scache
 
         c32 = {}

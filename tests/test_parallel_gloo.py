@@ -93,22 +93,28 @@ def graphed_worker(rank, world, port, out):
     net = nn.Sequential(PermutedLinear(6, 300, 40), nn.Tanh(), nn.Linear(300, 5))
     broadcast_parameters(net)
     red = GraphedGradAllReduce(list(net.parameters()), small_numel=4096)
+    flat = red.bucket.flat
+    inplace = True
     for _ in range(2):   # (what a graph replay leaves behind: fresh gradients in the same buffers)
-        for p in net.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
+        red.prepare()
         x, t = data(rank)
         ((net(x) - t) ** 2).sum().backward()
+        red.collect()
         red()
+        for p, v in zip(red.bucket.params, red.bucket.views):
+            inplace = inplace and p.grad.data_ptr() == v.data_ptr() and \
+                flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
     if rank == 0:
         torch.save({"grads": [p.grad.clone() for p in net.parameters()],
-                    "strides": [p.grad.stride() for p in net.parameters()]}, out)
+                    "strides": [p.grad.stride() for p in net.parameters()],
+                    "inplace": inplace,
+                    "flat": flat.clone()}, out)
     dist.destroy_process_group()
 
 
 def test_graphed_grad_allreduce_matches_mean_of_per_rank_grads(tmp_path):
-    """The exchange bench.py uses for N > 1 when the step is a HIP graph: in-place all-reduce of
-    the (static) gradient buffers after the replay."""
+    """The exchange bench.py uses for N > 1 when the step is a HIP graph: the gradients are
+    views of one flat buffer, all-reduced in place after the replay."""
     out = str(tmp_path / "g0.pt")
     mp.spawn(graphed_worker, args=(2, free_port(), out), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
@@ -124,7 +130,13 @@ def test_graphed_grad_allreduce_matches_mean_of_per_rank_grads(tmp_path):
             acc += p.grad / 2
     for g, w_, st, p in zip(got["grads"], want, got["strides"], net.parameters()):
         assert torch.allclose(g, w_, rtol=1e-5, atol=1e-6)
-        assert tuple(st) == tuple(p.stride())
+        assert tuple(st) == tuple(p.stride())  # strides of the permuted leaf kept
+    # every gradient IS a slice of the one flat buffer (no concatenation, no copy back), laid
+    # out in storage order: the flat buffer is the gradients' physical views end to end
+    assert got["inplace"]
+    phys = [g.permute(1, 2, 0) if g.dim() == 3 else g for g in got["grads"]]
+    assert all(v.is_contiguous() for v in phys)
+    assert torch.equal(got["flat"], torch.cat([v.reshape(-1) for v in phys]))
 
 
 def test_bench_spawns_its_own_ranks_and_reports_failures(capsys):
