@@ -23,8 +23,14 @@
 // Replaces autograd's index_put_(accumulate=True) scatter into w.grad (loss.backward() at
 // networks.py:164-165 of the reference), like pp_sort.hip; measured against it in
 // profiles/r02_e_layer_bench.txt.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pp_device.h"
-#include "pp_regacc_body.inc"
+#ifndef PP_REGACC_INC
+#define PP_REGACC_INC "pp_regacc_body.inc"
+#endif
+#include PP_REGACC_INC
 
 namespace {
 
@@ -39,6 +45,8 @@ struct RegaccPlan {
   int nquad;       // groups of 4 inputs (one workgroup = 4 waves = 4 inputs, same rows and outs)
   int sbps;        // super-blocks per slice
   int nslice;      // row slices (1 = tables go straight to gw)
+  bool lds;        // gy shared through LDS by the workgroup's four waves
+  bool packed;     // lds, n = 1: records are one byte a row
   size_t rec_ints_per_input;
   size_t off_rec, off_part, bytes;
 };
@@ -50,14 +58,34 @@ RegaccPlan make_plan(const PPShape& sh) {
   p.nchunk = (sh.O + 63) / 64;
   p.nquad = (sh.I + 3) / 4;
   const long waves_full = (long)sh.I * p.nchunk;
+  // gy through LDS where there is enough work to fill the chip with its 4-wave workgroups
+  // (tools/regacc_sweep.py, profiles/r03_e_regacc_lds.txt: 201 -> 121 us on the cfg3 hidden layer
+  // at 16384 rows, 63 -> 51 at 4096, even at 2048; behind for few inputs or small batches)
+  p.lds = (long)sh.B * p.nquad * p.nchunk >= 500000L;
+#ifdef PP_TUNING  // developer builds only
+  if (const char* e = getenv("PP_REGACC_LDS")) p.lds = atoi(e) != 0;
+#endif
   long ns = 1;
-  if (waves_full < 768) ns = (1024 + waves_full - 1) / waves_full;
+  if (p.lds) {
+    // two workgroups a CU (256 registers a wave): 512 resident at a time; one alone on a CU
+    // idles at its barriers (212 us unsliced on the cfg3 hidden layer, 106 + 12 in two slices)
+    ns = std::max<long>(1, 512 / ((long)p.nquad * p.nchunk));
+  } else if (waves_full < 768) {
+    ns = (1024 + waves_full - 1) / waves_full;
+  }
   ns = std::min<long>(ns, std::max<long>(1, p.nsb / 4));  // at least 256 rows per slice
   const size_t table = (size_t)sh.I * sh.K * sh.O * sizeof(float);
   ns = std::min<long>(ns, std::max<long>(1, (long)((96u << 20) / table)));
+#ifdef PP_TUNING  // developer builds only
+  if (const char* e = getenv("PP_REGACC_NSLICE")) ns = std::max(1, atoi(e));
+#endif
   p.sbps = (int)((p.nsb + ns - 1) / ns);
+  p.packed = p.lds && sh.n == 1;
+  if (p.packed) p.sbps = (p.sbps + 3) & ~3;  // slices start on a group of 256 rows
   p.nslice = (p.nsb + p.sbps - 1) / p.sbps;
-  p.rec_ints_per_input = (size_t)(p.nsb + 1) * planes_of(sh.n) * kSB;  // one super-block of slack
+  p.rec_ints_per_input = p.packed
+                             ? (size_t)((p.nsb + 3) / 4 + 1) * 64  // a byte a row, one group of slack
+                             : (size_t)(p.nsb + 1) * planes_of(sh.n) * kSB;  // one super-block of slack
   size_t o = 0;
   p.off_rec = o;
   o += ((size_t)sh.I * p.rec_ints_per_input * sizeof(int) + 255) & ~(size_t)255;
@@ -122,6 +150,44 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __rest
   }
 }
 
+// Packed records of the n = 1 LDS variant: rec8[i][row] = k0 of the row (< 256), 0 past the
+// batch.  One workgroup = 256 rows x 16 inputs, transposed through LDS.
+__global__ __launch_bounds__(256) void pp_regacc_prep_packed_kernel(const float* __restrict__ x,
+                                                                    int* __restrict__ rec,
+                                                                    PPShape sh,
+                                                                    size_t rec_ints_per_input) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[16][260];
+  const int t = threadIdx.x;
+  const int b0 = blockIdx.x * 256, i0 = blockIdx.y * 16;
+  {
+    const int col = t & 15, rp = t >> 4;
+    const int i = i0 + col;
+    float xv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int b = b0 + rr * 16 + rp;
+      xv[rr] = (b < sh.B && i < sh.I) ? x[(size_t)b * sh.I + i] : 0.0f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int b = b0 + rr * 16 + rp;
+      int k0 = 0;
+      if (b < sh.B && i < sh.I) k0 = pp_segment(xv[rr], sh.length, sh.half, sh.Sf, sh.S) * sh.stride;
+      tile[col][rr * 16 + rp] = (unsigned char)k0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    const int idx = t + 256 * pp;
+    const int col = idx >> 6, dw = idx & 63;
+    const int i = i0 + col;
+    if (i < sh.I)
+      rec[(size_t)i * rec_ints_per_input + (size_t)blockIdx.x * 64 + dw] =
+          *reinterpret_cast<const int*>(&tile[col][dw * 4]);
+  }
+}
+
 struct RegaccArgs {
   int B, I, O, K, nchunk, nquad, sbps, nblk;
   size_t rec_ints_per_input;
@@ -135,6 +201,15 @@ struct RegaccArgs {
                : [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [dst] "s"(d),            \
                  [rec] "s"(recp), [nblk] "s"(nblk), [rowb] "s"(rowb), [K] "s"(K),                 \
                  [scale] "s"(scale), [laneb] "v"(laneb), [vok] "v"(vok), [lane4] "v"(lane4)       \
+               : PP_REGACC_CLOBBERS)
+
+#define PP_REGACC_LDS_ASM(BODY)                                                                   \
+  asm volatile(BODY                                                                               \
+               :                                                                                  \
+               : [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [dst] "s"(d),            \
+                 [rec] "s"(recp), [nblk] "s"(nblk), [rowb] "s"(rowb), [K] "s"(K),                 \
+                 [scale] "s"(scale), [ldsw] "s"(ldsw), [laneb] "v"(laneb), [vok] "v"(vok),        \
+                 [lane4] "v"(lane4), [ldsr] "v"(ldsr), [dma0] "v"(dma0)                           \
                : PP_REGACC_CLOBBERS)
 
 // DEEP: the variant for K <= PP_REGACC_KDEEP (64 staging registers: gy loads run 3 blocks ahead).
@@ -187,6 +262,70 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* 
   }
 }
 
+// gy shared through LDS by the four waves of a workgroup (tools/gen_regacc_asm.py, body_lds):
+// O % 4 == 0 (16-byte DMA pieces).  A wave without an input of its own (I % 4 != 0) repeats the
+// last input and stores nothing: it still has to bring in its share of every block and meet the
+// barriers.
+template <int N, bool DEEP>
+__global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const float* __restrict__ gy,
+                                                                       const int* __restrict__ rec,
+                                                                       float* __restrict__ dst,
+                                                                       RegaccArgs a) {
+  constexpr int P = planes_of(N);
+  __shared__ __attribute__((aligned(1024))) float stage[2 * kSB * 64];  // two blocks of 64 rows x 64 outs
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  int bid = blockIdx.x;
+  const int q = bid % a.nquad;
+  bid /= a.nquad;
+  const int c = bid % a.nchunk;
+  const int slice = bid / a.nchunk;
+  const bool own = q * 4 + wave < a.I;
+  const int i = own ? q * 4 + wave : a.I - 1;
+  const int sb0 = slice * a.sbps;
+  const int blk0 = sb0 * (kSB / kRB);
+  // n = 1 counts blocks of 64 rows (packed records), the others blocks of 16; >= 1 by the plan
+  const int nblk = N == 1 ? min(a.sbps, (a.nblk + 3) / 4 - sb0)
+                          : min(a.sbps * (kSB / kRB), a.nblk - blk0);
+  const long row0 = (long)blk0 * kRB;
+  const unsigned long long gaddr = (unsigned long long)(gy + row0 * a.O);
+  const int r0 = (int)(unsigned)(gaddr & 0xffffffffull);
+  const int r1 = (int)(unsigned)((gaddr >> 32) & 0xffffull);
+  const int r2 = (int)(unsigned)(((long)a.B - row0) * a.O * 4);
+  const int r3 = 0x00020000;
+  const int* recp = rec + (size_t)i * a.rec_ints_per_input +
+                    (N == 1 ? (size_t)(sb0 / 4) * 64 : (size_t)sb0 * P * kSB);
+  float* d = dst + (size_t)slice * a.slice_stride + (size_t)i * a.K * a.O;
+  const int o = c * 64 + lane;
+  const int laneb = o * 4;
+  const int lane4 = lane * 4;
+  const int vok = (own && o < a.O) ? 1 : 0;
+  const int rowb = a.O * 4;
+  const int K = a.K;
+  const float scale = a.scale;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const unsigned ldsbase = (unsigned)(__UINTPTR_TYPE__)(lds_void*)stage;
+  const int ldsw = (int)(ldsbase + (unsigned)wave * 1024u);
+  const int ldsr = (int)(ldsbase + (unsigned)lane * 4u);
+  // source of this lane's 16 bytes of the wave's first DMA piece: row 4*wave + lane/16 of the
+  // block, outs c*64 + 4*(lane%16) .. +3 (past the end of a row: the next row's values, or the
+  // 0 of the range check, in cells no lane with an out reads)
+  const int dma0 = ((lane >> 4) + 4 * wave) * rowb + c * 256 + (lane & 15) * 16;
+  if constexpr (N == 1 && DEEP) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS1_BODY_K160);
+  } else if constexpr (N == 1) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS1_BODY_K192);
+  } else if constexpr (N == 2 && DEEP) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N2_K160);
+  } else if constexpr (N == 2) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N2_K192);
+  } else if constexpr (DEEP) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N3_K160);
+  } else {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N3_K192);
+  }
+}
+
 template <int N>
 hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const PPShape& sh,
                   const BasisTab& tab, hipStream_t st) {
@@ -194,9 +333,12 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
   char* base = static_cast<char*>(ws);
   int* rec = reinterpret_cast<int*>(base + p.off_rec);
   float* part = reinterpret_cast<float*>(base + p.off_part);
-  // the slack super-block is written too (zeros)
-  hipLaunchKernelGGL((pp_regacc_prep_kernel<N>), dim3(p.nsb + 1, (sh.I + 31) / 32), dim3(256), 0,
-                     st, x, rec, sh, tab, p.rec_ints_per_input);
+  if (p.packed)
+    hipLaunchKernelGGL(pp_regacc_prep_packed_kernel, dim3((p.nsb + 3) / 4, (sh.I + 15) / 16),
+                       dim3(256), 0, st, x, rec, sh, p.rec_ints_per_input);
+  else  // the slack super-block is written too (zeros)
+    hipLaunchKernelGGL((pp_regacc_prep_kernel<N>), dim3(p.nsb + 1, (sh.I + 31) / 32), dim3(256), 0,
+                       st, x, rec, sh, tab, p.rec_ints_per_input);
   RegaccArgs a;
   a.B = sh.B; a.I = sh.I; a.O = sh.O; a.K = sh.K;
   a.nchunk = p.nchunk; a.nquad = p.nquad; a.sbps = p.sbps; a.nblk = p.nblk;
@@ -205,7 +347,14 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
   a.scale = p.nslice > 1 ? 1.0f : sh.out_scale;
   float* dst = p.nslice > 1 ? part : gwt;
   const dim3 grid(p.nquad * p.nchunk * p.nslice);
-  if (sh.K <= PP_REGACC_KDEEP)
+  if (p.lds) {
+    if (sh.K <= PP_REGACC_KDEEP)
+      hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<N, true>), grid, dim3(256), 0, st, gy,
+                         (const int*)rec, dst, a);
+    else
+      hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<N, false>), grid, dim3(256), 0, st, gy,
+                         (const int*)rec, dst, a);
+  } else if (sh.K <= PP_REGACC_KDEEP)
     hipLaunchKernelGGL((pp_bwd_weight_regacc_kernel<N, true>), grid, dim3(256), 0, st, gy,
                        (const int*)rec, dst, a);
   else

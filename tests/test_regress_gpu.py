@@ -188,7 +188,8 @@ def test_slab_forward_matches_oracle_and_gather(case):
 
 # (disc, n, S, I, O, B, dist, out_scale): shapes of the register-accumulator weight gradient --
 # both register layouts (K <= 160 / <= 192), n = 1..3, batches that end inside a block of 16 and
-# inside a set of 64 rows, sliced (few inputs) and unsliced grids, ragged out chunks
+# inside a set of 64 rows, sliced (few inputs) and unsliced grids, ragged out chunks, gy loaded
+# by every wave (small layers / batches) and shared through LDS (large ones)
 REGACC_CASES = [
     (True, 1, 150, 200, 200, 4096, "normal", 1.0),      # cfg3 hidden layer
     (True, 1, 150, 200, 200, 1000, "normal", 1.0),      # ... at the reference's batch
@@ -199,6 +200,11 @@ REGACC_CASES = [
     (True, 3, 64, 5, 64, 129, "normal", 2.0),           # K = 192: the shallow register layout
     (True, 1, 192, 3, 1, 17, "uniform", 1.0),           # one out, less than one block of rows
     (False, 2, 191, 9, 130, 2049, "normal", 1.0),       # K = 192 continuous
+    # gy through LDS (batch x workgroups-per-slice >= 500 k; the first case above too):
+    (True, 1, 192, 130, 260, 3107, "normal", 1.0),      # byte records, K = 192, two waves without an input, 4-out tail
+    (True, 2, 64, 16, 1000, 16379, "char", 0.5),        # n = 2, eight slices, ragged rows
+    (True, 3, 64, 66, 250, 7501, "edges", 1.0),         # n = 3, K = 192, rows of 1000 bytes (8-byte aligned only)
+    (False, 2, 150, 64, 256, 8200, "normal", 1.0),      # continuous, K = 151
 ]
 
 

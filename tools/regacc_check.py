@@ -5,6 +5,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from language_interpolation_amd import _lib  # noqa: E402
+
+if os.environ.get("PP_LIB"):
+    _lib.LIB_PATH = os.environ["PP_LIB"]
 from language_interpolation_amd import functional as PF  # noqa: E402
 
 CASES = [
@@ -18,6 +22,10 @@ CASES = [
     (False, 3, 50, 37, 70, 777),
     (True, 3, 64, 5, 64, 129),
     (True, 1, 192, 3, 1, 17),
+    (True, 1, 150, 200, 200, 2049),
+    (True, 2, 80, 6, 72, 3000),
+    (False, 3, 50, 37, 68, 2111),
+    (True, 1, 160, 9, 4, 100),
 ]
 
 
@@ -25,7 +33,7 @@ def main():
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(1)
     bad = 0
-    for disc, n, S, I, O, B in CASES:
+    for disc, n, S, I, O, B in sorted(CASES, key=lambda c: c[4] % 4 != 0):
         K = PF.num_weights(n, S, disc)
         x = (torch.rand(B, I, generator=gen) * 2.2 - 1.1).to(dev)
         gy = torch.randn(B, O, generator=gen).to(dev)
