@@ -144,7 +144,8 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
         return pp_bf3_bwd_w_supported(sh) && B >= (O > 128 ? 4096 : 8192) ? PP_BWD_W_FP16X2
                                                                          : PP_BWD_W_DENSE;
       if (pp_regacc_preferred(sh)) return PP_BWD_W_REGACC;
-      if (pp_regacc_supported(sh)) return PP_BWD_W_ATOMIC;  // too small for anything but atomics
+      if (pp_regacc_supported(sh) && pp_regacc_parts(sh) == 1)
+        return PP_BWD_W_ATOMIC;  // too small for anything but atomics
       // more weight rows per input than the register accumulators hold, at the reference's
       // batch sizes: the row-owner kernel (16 -> 1000, K = 256: 17 us against 42-45 at 256 rows,
       // level with the sort at ~700; profiles/r02_q_small_batch_bwd_w.txt)

@@ -59,6 +59,7 @@ hipError_t pp_launch_bwd_weight_sort(const float* x, const float* gy, float* gwt
 bool pp_direct_supported(const PPShape& sh);  // B <= 1024, n <= 4
 hipError_t pp_launch_bwd_weight_direct(const float* x, const float* gy, float* gwt,
                                        const PPShape& sh, const BasisTab& tab, hipStream_t st);
+int pp_regacc_parts(const PPShape& sh);  // waves an input (1: K <= 192)
 bool pp_regacc_supported(const PPShape& sh);
 bool pp_regacc_preferred(const PPShape& sh);
 size_t pp_regacc_workspace_bytes(const PPShape& sh);

@@ -45,6 +45,8 @@ struct RegaccPlan {
   int nquad;       // groups of 4 inputs (one workgroup = 4 waves = 4 inputs, same rows and outs)
   int sbps;        // super-blocks per slice
   int nslice;      // row slices (1 = tables go straight to gw)
+  int H;           // parts the table rows of an input are cut into (K > 192: one wave a part)
+  int KH;          // table rows a part
   bool lds;        // gy shared through LDS by the workgroup's four waves
   bool packed;     // lds, n = 1: records are one byte a row
   size_t rec_ints_per_input;
@@ -56,8 +58,14 @@ RegaccPlan make_plan(const PPShape& sh) {
   p.nblk = (sh.B + kRB - 1) / kRB;
   p.nsb = (sh.B + kSB - 1) / kSB;
   p.nchunk = (sh.O + 63) / 64;
-  p.nquad = (sh.I + 3) / 4;
-  const long waves_full = (long)sh.I * p.nchunk;
+  // More table rows than accumulator registers (discontinuous, n >= 2 only): H waves an input,
+  // each with the rows of S/H segments; a batch row outside a wave's segments is given k0 = 0
+  // and zero basis values by the prepass (it adds 0), so the loop does not change.
+  p.H = (sh.K + PP_REGACC_KMAX - 1) / PP_REGACC_KMAX;
+  p.KH = p.H == 1 ? sh.K : (sh.S + p.H - 1) / p.H * sh.stride;
+  const int IV = sh.I * p.H;
+  p.nquad = (IV + 3) / 4;
+  const long waves_full = (long)IV * p.nchunk;
   // gy through LDS where there is enough work to fill the chip with its 4-wave workgroups
   // (tools/regacc_sweep.py, profiles/r03_e_regacc_lds.txt: 201 -> 121 us on the cfg3 hidden layer
   // at 16384 rows, 63 -> 51 at 4096, even at 2048; behind for few inputs or small batches)
@@ -88,7 +96,7 @@ RegaccPlan make_plan(const PPShape& sh) {
                              : (size_t)(p.nsb + 1) * planes_of(sh.n) * kSB;  // one super-block of slack
   size_t o = 0;
   p.off_rec = o;
-  o += ((size_t)sh.I * p.rec_ints_per_input * sizeof(int) + 255) & ~(size_t)255;
+  o += ((size_t)sh.I * p.H * p.rec_ints_per_input * sizeof(int) + 255) & ~(size_t)255;
   p.off_part = o;
   if (p.nslice > 1) o += (size_t)p.nslice * table;
   p.bytes = o;
@@ -103,7 +111,8 @@ template <int N>
 __global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __restrict__ x,
                                                              int* __restrict__ rec, PPShape sh,
                                                              BasisTab tab,
-                                                             size_t rec_ints_per_input) {
+                                                             size_t rec_ints_per_input, int H,
+                                                             int KH) {
   constexpr int P = planes_of(N);
   __shared__ int tile[P][32][65];
   const int t = threadIdx.x;
@@ -142,9 +151,19 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __rest
       const int col = cc * 4 + cp;
       const int i = i0 + col;
       if (i < sh.I) {
-        int* dst = rec + (size_t)i * rec_ints_per_input + (size_t)blockIdx.x * P * kSB + rl;
+        int* dst = rec + (size_t)i * H * rec_ints_per_input + (size_t)blockIdx.x * P * kSB + rl;
+        if (H == 1) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) dst[j * kSB] = tile[j][col][rl];
+          for (int j = 0; j < P; ++j) dst[j * kSB] = tile[j][col][rl];
+        } else {  // one record set a part: the row counts in the part its segment lies in only
+          const int k0 = tile[0][col][rl];
+          const int part = k0 / KH;
+          for (int h = 0; h < H; ++h, dst += rec_ints_per_input) {
+            dst[0] = h == part ? k0 - part * KH : 0;
+#pragma unroll
+            for (int j = 1; j < P; ++j) dst[j * kSB] = h == part ? tile[j][col][rl] : 0;
+          }
+        }
       }
     }
   }
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_packed_kernel(const float*
 }
 
 struct RegaccArgs {
-  int B, I, O, K, nchunk, nquad, sbps, nblk;
+  int B, I, O, K, nchunk, nquad, sbps, nblk, H, KH;
   size_t rec_ints_per_input;
   size_t slice_stride;  // floats between the tables of two slices
   float scale;
@@ -226,8 +245,9 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* 
   bid /= a.nquad;
   const int c = bid % a.nchunk;
   const int slice = bid / a.nchunk;
-  const int i = q * 4 + wave;
-  if (i >= a.I) return;  // whole wave
+  const int iv = q * 4 + wave;  // input i, part h of its table rows
+  if (iv >= a.I * a.H) return;  // whole wave
+  const int i = iv / a.H, h = iv - i * a.H;
   const int sb0 = slice * a.sbps;
   const int blk0 = sb0 * (kSB / kRB);
   const int nblk = min(a.sbps * (kSB / kRB), a.nblk - blk0);  // >= 1 by the plan
@@ -238,14 +258,14 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* 
   const int r1 = (int)(unsigned)((gaddr >> 32) & 0xffffull);
   const int r2 = (int)(unsigned)(((long)a.B - row0) * a.O * 4);
   const int r3 = 0x00020000;
-  const int* recp = rec + (size_t)i * a.rec_ints_per_input + (size_t)sb0 * P * kSB;
-  float* d = dst + (size_t)slice * a.slice_stride + (size_t)i * a.K * a.O;
+  const int* recp = rec + (size_t)iv * a.rec_ints_per_input + (size_t)sb0 * P * kSB;
+  float* d = dst + (size_t)slice * a.slice_stride + ((size_t)i * a.K + (size_t)h * a.KH) * a.O;
   const int o = c * 64 + lane;
   const int laneb = o * 4;
   const int lane4 = lane * 4;
   const int vok = o < a.O ? 1 : 0;
   const int rowb = a.O * 4;
-  const int K = a.K;
+  const int K = min(a.KH, a.K - h * a.KH);
   const float scale = a.scale;
   if constexpr (N == 1 && DEEP) {
     PP_REGACC_ASM(PP_REGACC_BODY_N1_K160);
@@ -280,8 +300,9 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const flo
   bid /= a.nquad;
   const int c = bid % a.nchunk;
   const int slice = bid / a.nchunk;
-  const bool own = q * 4 + wave < a.I;
-  const int i = own ? q * 4 + wave : a.I - 1;
+  const bool own = q * 4 + wave < a.I * a.H;
+  const int iv = own ? q * 4 + wave : a.I * a.H - 1;  // input i, part h of its table rows
+  const int i = iv / a.H, h = iv - i * a.H;
   const int sb0 = slice * a.sbps;
   const int blk0 = sb0 * (kSB / kRB);
   // n = 1 counts blocks of 64 rows (packed records), the others blocks of 16; >= 1 by the plan
@@ -293,15 +314,15 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const flo
   const int r1 = (int)(unsigned)((gaddr >> 32) & 0xffffull);
   const int r2 = (int)(unsigned)(((long)a.B - row0) * a.O * 4);
   const int r3 = 0x00020000;
-  const int* recp = rec + (size_t)i * a.rec_ints_per_input +
+  const int* recp = rec + (size_t)iv * a.rec_ints_per_input +
                     (N == 1 ? (size_t)(sb0 / 4) * 64 : (size_t)sb0 * P * kSB);
-  float* d = dst + (size_t)slice * a.slice_stride + (size_t)i * a.K * a.O;
+  float* d = dst + (size_t)slice * a.slice_stride + ((size_t)i * a.K + (size_t)h * a.KH) * a.O;
   const int o = c * 64 + lane;
   const int laneb = o * 4;
   const int lane4 = lane * 4;
   const int vok = (own && o < a.O) ? 1 : 0;
   const int rowb = a.O * 4;
-  const int K = a.K;
+  const int K = min(a.KH, a.K - h * a.KH);
   const float scale = a.scale;
   typedef __attribute__((address_space(3))) void lds_void;
   const unsigned ldsbase = (unsigned)(__UINTPTR_TYPE__)(lds_void*)stage;
@@ -338,23 +359,24 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
                        dim3(256), 0, st, x, rec, sh, p.rec_ints_per_input);
   else  // the slack super-block is written too (zeros)
     hipLaunchKernelGGL((pp_regacc_prep_kernel<N>), dim3(p.nsb + 1, (sh.I + 31) / 32), dim3(256), 0,
-                       st, x, rec, sh, tab, p.rec_ints_per_input);
+                       st, x, rec, sh, tab, p.rec_ints_per_input, p.H, p.KH);
   RegaccArgs a;
   a.B = sh.B; a.I = sh.I; a.O = sh.O; a.K = sh.K;
   a.nchunk = p.nchunk; a.nquad = p.nquad; a.sbps = p.sbps; a.nblk = p.nblk;
+  a.H = p.H; a.KH = p.KH;
   a.rec_ints_per_input = p.rec_ints_per_input;
   a.slice_stride = (size_t)sh.I * sh.K * sh.O;
   a.scale = p.nslice > 1 ? 1.0f : sh.out_scale;
   float* dst = p.nslice > 1 ? part : gwt;
   const dim3 grid(p.nquad * p.nchunk * p.nslice);
   if (p.lds) {
-    if (sh.K <= PP_REGACC_KDEEP)
+    if (p.KH <= PP_REGACC_KDEEP)
       hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<N, true>), grid, dim3(256), 0, st, gy,
                          (const int*)rec, dst, a);
     else
       hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<N, false>), grid, dim3(256), 0, st, gy,
                          (const int*)rec, dst, a);
-  } else if (sh.K <= PP_REGACC_KDEEP)
+  } else if (p.KH <= PP_REGACC_KDEEP)
     hipLaunchKernelGGL((pp_bwd_weight_regacc_kernel<N, true>), grid, dim3(256), 0, st, gy,
                        (const int*)rec, dst, a);
   else
@@ -367,15 +389,28 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
 
 }  // namespace
 
+int pp_regacc_parts(const PPShape& sh) { return (sh.K + PP_REGACC_KMAX - 1) / PP_REGACC_KMAX; }
+
 bool pp_regacc_supported(const PPShape& sh) {
-  return sh.K <= PP_REGACC_KMAX && sh.n <= 3 && (long)sh.B * sh.O * 4 < (1L << 31) &&
-         (long)sh.O * 4 * 16 < (1L << 24);
+  const int H = pp_regacc_parts(sh);
+  // more rows than registers: whole segments to a part, which a shared node (continuous) or an
+  // all-ones basis (n = 1: the row outside its part has nothing to multiply by 0) rules out
+  if (H > 1 && (!sh.disc || sh.n < 2 || H > 3 ||
+                (sh.S + H - 1) / H * sh.stride > PP_REGACC_KMAX))
+    return false;
+  return sh.n <= 3 && (long)sh.B * sh.O * 4 < (1L << 31) && (long)sh.O * 4 * 16 < (1L << 24);
 }
 
 // Where it measured fastest (profiles/r02_e_layer_bench.txt): every supported shape, except the
-// very small ones where a few million float atomics are cheaper than its three launches.
+// very small ones where a few million float atomics are cheaper than its three launches.  In
+// parts (K > 192) every wave walks all rows for the table rows of its part: still ahead of the
+// sort at every batch the row-owner kernel does not take (cfg4 input 16 -> 1000, K = 256: 35 vs
+// 50 us at 1000 rows, 124 vs 209 at 16384; 200 -> 200 with K = 300: 48 vs 146 and 394 vs 531;
+// profiles/r03_e_regacc_lds.txt).
 bool pp_regacc_preferred(const PPShape& sh) {
-  return pp_regacc_supported(sh) && (long)sh.B * sh.I * sh.n * sh.O >= 2500000L;
+  if (!pp_regacc_supported(sh)) return false;
+  if (pp_regacc_parts(sh) > 1) return sh.B > 512;
+  return (long)sh.B * sh.I * sh.n * sh.O >= 2500000L;
 }
 
 size_t pp_regacc_workspace_bytes(const PPShape& sh) { return make_plan(sh).bytes; }

@@ -52,18 +52,24 @@ def test_auto_method_selection():
     lib = _lib.load()
     # many segments -> gather / sort
     assert lib.pp_auto_method(0, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.FWD_GATHER
-    assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.BWD_W_SORT
-    # ... up to 192 weight rows per input and n <= 3: accumulators in registers
+    assert lib.pp_auto_method(2, 1024, 16, 1000, 4, 64, 1, 2.0) == _lib.BWD_W_SORT
+    # ... up to 192 weight rows per input (or whole segments to 2-3 waves, discontinuous) and
+    # n <= 3: accumulators in registers
     assert lib.pp_auto_method(2, 1000, 200, 200, 1, 150, 1, 2.0) == _lib.BWD_W_REGACC
     assert lib.pp_auto_method(2, 16384, 16, 250, 2, 128, 0, 2.0) == _lib.BWD_W_REGACC
     assert lib.pp_auto_method(2, 64, 16, 250, 2, 128, 0, 2.0) == _lib.BWD_W_ATOMIC  # tiny
-    assert lib.pp_auto_method(2, 4096, 200, 200, 2, 150, 1, 2.0) == _lib.BWD_W_SORT  # K = 300
+    assert lib.pp_auto_method(2, 4096, 200, 200, 2, 150, 1, 2.0) == _lib.BWD_W_REGACC  # K = 300: two parts
+    assert lib.pp_auto_method(2, 1024, 16, 1000, 2, 128, 1, 2.0) == _lib.BWD_W_REGACC  # cfg4 input
+    assert lib.pp_auto_method(2, 256, 16, 1000, 2, 128, 1, 2.0) == _lib.BWD_W_DIRECT   # ... reference batch
+    assert lib.pp_auto_method(2, 4096, 64, 64, 2, 200, 0, 2.0) == _lib.BWD_W_SORT      # K = 201 continuous
+    assert lib.pp_auto_method(2, 4096, 64, 64, 1, 300, 1, 2.0) == _lib.BWD_W_SORT      # K = 300, n = 1
     assert lib.pp_auto_method(2, 4096, 64, 64, 4, 40, 1, 2.0) == _lib.BWD_W_SORT     # n = 4
     assert lib.pp_workspace_bytes(1000, 200, 200, 1, 150, 1, 2.0, _lib.BWD_W_REGACC) > 0
-    assert lib.pp_workspace_bytes(1000, 16, 1000, 2, 128, 1, 2.0, _lib.BWD_W_REGACC) == 0  # K = 256
+    assert lib.pp_workspace_bytes(1000, 16, 1000, 2, 128, 0, 2.0, _lib.BWD_W_REGACC) > 0
+    assert lib.pp_workspace_bytes(1000, 16, 1000, 2, 200, 0, 2.0, _lib.BWD_W_REGACC) == 0  # K = 201 continuous
     null = ctypes.c_void_p(0)
     fake = ctypes.c_void_p(0x1000)
-    assert lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 1000, 16, 1000, 2, 128, 1, 2.0,
+    assert lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 1000, 16, 1000, 2, 200, 0, 2.0,
                                       null, 1.0, _lib.BWD_W_REGACC, null) == -5  # not this shape
     assert lib.pp_backward_weight_f32(fake, fake, fake, null, 0, 1000, 200, 200, 1, 150, 1, 2.0,
                                       null, 1.0, _lib.BWD_W_REGACC, null) == -4  # no workspace

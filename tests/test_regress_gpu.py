@@ -205,6 +205,11 @@ REGACC_CASES = [
     (True, 2, 64, 16, 1000, 16379, "char", 0.5),        # n = 2, eight slices, ragged rows
     (True, 3, 64, 66, 250, 7501, "edges", 1.0),         # n = 3, K = 192, rows of 1000 bytes (8-byte aligned only)
     (False, 2, 150, 64, 256, 8200, "normal", 1.0),      # continuous, K = 151
+    # more table rows than accumulator registers: 2 or 3 waves an input, whole segments each
+    (True, 2, 128, 16, 1000, 16384 - 7, "char", 1.0),   # cfg4 input layer (K = 256), gy through LDS
+    (True, 2, 128, 16, 1000, 1000, "char", 1.0),        # ... at the reference's batch (gy by every wave)
+    (True, 2, 150, 200, 200, 1500, "normal", 0.25),     # cfg3 with the n_hidden quirk (K = 300, 75 segments a part)
+    (True, 3, 190, 6, 70, 1333, "edges", 1.0),          # K = 570: three parts of 64 / 64 / 62 segments
 ]
 
 
@@ -215,6 +220,8 @@ def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
     lib = _lib.load()
     K = n * S if disc else (n - 1) * S + 1
     want = _lib.BWD_W_REGACC if B * I * n * O >= 2500000 else _lib.BWD_W_ATOMIC
+    if K > 192:
+        want = _lib.BWD_W_REGACC if B > 512 else _lib.BWD_W_DIRECT
     assert lib.pp_auto_method(2, B, I, O, n, S, int(disc), 2.0) == want, "planner"
     PF = _pf()
     x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=90 + n)

@@ -302,8 +302,9 @@ READ1 = "--read1" in sys.argv   # developer variant: one ds_read_b32 a row inste
 def body_lds1(KMAX):
     """n = 1 with gy through LDS (body_lds) and PACKED records: the only per-row scalar is the
     table row k0 < 256, so the records are one byte a row (rec8[i][row]) and one v_readlane brings
-    four rows' indices into an SGPR; s_set_gpr_idx_idx takes bits 7:0, an s_lshr_b32 (SALU, off
-    the vector pipe) moves the next byte down.  v_readlane was 7-8 of the ~17 cycles a row of
+    four rows' indices into an SGPR; s_set_gpr_idx_idx takes bits 7:0, an s_lshr_b64 (SALU, off
+    the vector pipe) moves the next byte of two registers down (106 -> 97 us against one
+    s_lshr_b32 a row; the indices by s_load_dwordx16 instead of v_readlane: no difference).  v_readlane was 7-8 of the ~17 cycles a row of
     body_lds; here it is 16 per 64 rows, all issued at the top of the block, so the index mode
     stays on for the 64 accumulates of a block (the mode switches were the other large item).
     One record register holds 256 rows (v8; the next 256 are loaded into v12 a group ahead), the
@@ -382,14 +383,17 @@ def body_lds1(KMAX):
                 a(f"s_waitcnt lgkmcnt({8 if READ1 else 4})")
             else:
                 a("s_waitcnt lgkmcnt(0)")
-            for r in range(8):
-                row = h * 8 + r
-                sreg = IDX0 + row // 4
-                if row and not X_NOIDX:
-                    a(f"s_set_gpr_idx_idx s{sreg}")
-                a(f"v_add_f32 v{ACC0}, v{cur + r}, v{ACC0}")
-                if row % 4 != 3 and not X_NOLSHR:
-                    a(f"s_lshr_b32 s{sreg}, s{sreg}, 8")
+            # the 8 rows of this half: bytes of the register pair s[lo:lo+1]; one 64-bit shift
+            # moves the next byte of BOTH registers down, so the rows go 0,4,1,5,2,6,3,7
+            lo = IDX0 + 2 * h
+            for j in range(4):
+                for w in range(2):
+                    r = 4 * w + j
+                    if h or j or w:
+                        a(f"s_set_gpr_idx_idx s{lo + w}")
+                    a(f"v_add_f32 v{ACC0}, v{cur + r}, v{ACC0}")
+                if j < 3 and not X_NOLSHR:
+                    a(f"s_lshr_b64 s[{lo}:{lo + 1}], s[{lo}:{lo + 1}], 8")
         a("s_set_gpr_idx_off")
         a("s_sub_u32 s35, s35, 1")
         a("s_cmp_eq_u32 s35, 0")

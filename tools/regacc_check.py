@@ -26,6 +26,10 @@ CASES = [
     (True, 2, 80, 6, 72, 3000),
     (False, 3, 50, 37, 68, 2111),
     (True, 1, 160, 9, 4, 100),
+    (True, 2, 128, 16, 1000, 16384),
+    (True, 2, 128, 16, 1000, 1000),
+    (True, 2, 150, 200, 200, 4099),
+    (True, 3, 190, 6, 70, 333),
 ]
 
 

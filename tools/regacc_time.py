@@ -11,7 +11,8 @@ if os.environ.get("PP_LIB"):
     _lib.LIB_PATH = os.environ["PP_LIB"]
 from language_interpolation_amd import functional as PF  # noqa: E402
 
-SHAPES = [(True, 1, 150, 200, 200, 16384), (False, 2, 128, 16, 250, 16384), (True, 2, 64, 16, 1000, 16384)]
+SHAPES = [(True, 1, 150, 200, 200, 16384), (False, 2, 128, 16, 250, 16384), (True, 2, 64, 16, 1000, 16384),
+          (True, 2, 128, 16, 1000, 16384), (True, 2, 150, 200, 200, 16384)]
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(1)
 for disc, n, S, I, O, B in SHAPES:
