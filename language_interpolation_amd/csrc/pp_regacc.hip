@@ -20,6 +20,20 @@
 // compiler has no way to express a register-indexed accumulate (an indexed array of this size is
 // placed in scratch memory).
 //
+// Round 3 (profiles/r03_e_regacc_lds.txt):
+//  * gy through LDS (pp_bwd_weight_regacc_lds_kernel): the four waves of a workgroup -- four
+//    inputs, the same rows and outs -- used to load every gy row themselves, and that load path
+//    was what the kernel ran at.  Now a block of 64 rows x 256 bytes is copied ONCE per workgroup
+//    into one of two LDS buffers by LDS-DMA while the waves accumulate out of the other
+//    (ds_read2st64_b32: two rows an instruction).  For n = 1 the records are one byte a row and
+//    the index mode stays on for 64 rows; for discontinuous n = 2 (k0 even) the two accumulators
+//    of a row are an aligned register pair and take ONE indexed v_pk_fma_f32.  Used where
+//    rows x workgroups >= 500 k; the per-wave-load kernel keeps the small layers and batches.
+//  * K > 192 (discontinuous, n >= 2): the table rows of an input go to 2-3 waves by whole
+//    segments ("parts"); the prepass gives a batch row k0 = 0 and zero basis values in the
+//    record sets of the parts its segment is not in, so every wave still walks all rows with the
+//    same loop and adds 0 for the rows of the others.
+//
 // Replaces autograd's index_put_(accumulate=True) scatter into w.grad (loss.backward() at
 // networks.py:164-165 of the reference), like pp_sort.hip; measured against it in
 // profiles/r02_e_layer_bench.txt.
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* 
 // O % 4 == 0 (16-byte DMA pieces).  A wave without an input of its own (I % 4 != 0) repeats the
 // last input and stores nothing: it still has to bring in its share of every block and meet the
 // barriers.
-template <int N, bool DEEP>
+template <int N, bool DEEP, bool PK = false>
 __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const float* __restrict__ gy,
                                                                        const int* __restrict__ rec,
                                                                        float* __restrict__ dst,
@@ -336,6 +350,10 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const flo
     PP_REGACC_LDS_ASM(PP_REGACC_LDS1_BODY_K160);
   } else if constexpr (N == 1) {
     PP_REGACC_LDS_ASM(PP_REGACC_LDS1_BODY_K192);
+  } else if constexpr (N == 2 && PK && DEEP) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N2PK_K160);
+  } else if constexpr (N == 2 && PK) {
+    PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N2PK_K192);
   } else if constexpr (N == 2 && DEEP) {
     PP_REGACC_LDS_ASM(PP_REGACC_LDS_BODY_N2_K160);
   } else if constexpr (N == 2) {
@@ -369,6 +387,23 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
   a.scale = p.nslice > 1 ? 1.0f : sh.out_scale;
   float* dst = p.nslice > 1 ? part : gwt;
   const dim3 grid(p.nquad * p.nchunk * p.nslice);
+  bool pk = N == 2 && sh.disc;  // k0 even: one packed FMA a row
+#ifdef PP_TUNING  // developer builds only
+  if (const char* e = getenv("PP_REGACC_PK")) pk = pk && atoi(e) != 0;
+#endif
+  if constexpr (N == 2) {
+    if (p.lds && pk) {
+      if (p.KH <= PP_REGACC_KDEEP)
+        hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<2, true, true>), grid, dim3(256), 0, st,
+                           gy, (const int*)rec, dst, a);
+      else
+        hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<2, false, true>), grid, dim3(256), 0,
+                           st, gy, (const int*)rec, dst, a);
+      if (p.nslice > 1)
+        pp_launch_chunk_reduce(part, gwt, (long)sh.I * sh.K * sh.O, p.nslice, sh.out_scale, st);
+      return hipGetLastError();
+    }
+  }
   if (p.lds) {
     if (p.KH <= PP_REGACC_KDEEP)
       hipLaunchKernelGGL((pp_bwd_weight_regacc_lds_kernel<N, true>), grid, dim3(256), 0, st, gy,

@@ -162,11 +162,10 @@ def test_slab_forward_matches_oracle_and_gather(case):
     from language_interpolation_amd import _lib
     disc, n, S, I, O, B, dist = case
     lib = _lib.load()
-    # PP_METHOD_AUTO takes the slab only where it measured faster (large tables, large batch)
-    K = n * S if disc else (n - 1) * S + 1
-    big = B >= 4096 and K >= 192 and I <= 32 and I * K * O * 4 >= (8 << 20)
-    want = _lib.FWD_SLAB if big else _lib.FWD_GATHER
-    assert lib.pp_auto_method(0, B, I, O, n, S, int(disc), 2.0) == want, "planner"
+    # PP_METHOD_AUTO no longer takes the slab (round 3: behind the gather kernel on batches with
+    # the reference text's character histogram, behind the row-tile kernel at large batches);
+    # the kernel stays selectable by name
+    assert lib.pp_auto_method(0, B, I, O, n, S, int(disc), 2.0) == _lib.FWD_GATHER, "planner"
     PF = _pf()
     x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=70 + n)
     xd = x.cuda()

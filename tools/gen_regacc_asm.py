@@ -151,11 +151,11 @@ def body(N, KMAX):
     return L
 
 
-def body_lds(N, KMAX):
+def body_lds(N, KMAX, PK=False):
     """Variant with gy shared through LDS (round 3).  The four waves of a workgroup (four inputs,
     same rows, same 64 outs) each loaded every gy row themselves: 3.4 GB through the vector-memory
     path per launch on the cfg3 hidden layer, which is what its 180-190 us were (without the loads
-    the loop takes 134 us at one wave per SIMD and 90 us at two; profiles/r03_e_regacc_ablation.txt).
+    the loop takes 134 us at one wave per SIMD and 90 us at two; profiles/r03_e_regacc_lds.txt).
     Here a block of 64 rows x 256 bytes is brought into one of two LDS buffers ONCE per workgroup by
     LDS-DMA (buffer_load_dwordx4 ... lds, four instructions per wave, the buffer resource still
     returns 0 past the end of the batch) while the waves accumulate the previous block out of the
@@ -166,10 +166,15 @@ def body_lds(N, KMAX):
       v[20:23] DMA source offsets of this wave's four pieces (rows 4(w+4t)..+3, t = 0..3)
       v[32:39], v[40:47] two sets of 8 gy values (first / second half of a block of 16 rows)
       s34 bytes per 64 rows of gy     s22 scratch     s23 LDS address of this wave's first DMA piece
+    PK (n = 2, discontinuous: k0 even, so the two accumulators of a row are an aligned register
+    pair): ONE indexed v_pk_fma_f32 a row instead of two v_fma_f32 -- the indexed VALU operation
+    is what the loop is bound by (8 cycles each, measured on the n = 1 body).  The basis values
+    of row r sit in the aligned pair s[52+2r:53+2r]; gy is the low or the high half of an aligned
+    staging pair (op_sel).
     """
     P = 1 if N == 1 else 1 + N
     ACC0 = 256 - KMAX
-    assert ACC0 >= 48 and SC0 + P * RB <= 100
+    assert ACC0 >= 48 and SC0 + P * RB <= 100 and (not PK or N == 2)
     SA, SB_ = 32, 40
     L = []
     a = L.append
@@ -199,10 +204,17 @@ def body_lds(N, KMAX):
     def readlanes(ph, base):
         for j in range(P):
             for r in range(RB):
-                a(f"v_readlane_b32 s{SC0 + j * RB + r}, v{base + j}, {ph * RB + r}")
+                dst = SC0 + j * RB + r if not (PK and j) else SC0 + RB + 2 * r + j - 1
+                a(f"v_readlane_b32 s{dst}, v{base + j}, {ph * RB + r}")
 
     def accumulate(r, g):
-        if N == 1:
+        if PK:
+            m = SC0 + RB + 2 * r
+            if g % 2 == 0:
+                a(f"v_pk_fma_f32 v[{ACC0}:{ACC0 + 1}], s[{m}:{m + 1}], v[{g}:{g + 1}], v[{ACC0}:{ACC0 + 1}] op_sel_hi:[1,0,1]")
+            else:
+                a(f"v_pk_fma_f32 v[{ACC0}:{ACC0 + 1}], s[{m}:{m + 1}], v[{g - 1}:{g}], v[{ACC0}:{ACC0 + 1}] op_sel:[0,1,0] op_sel_hi:[1,1,1]")
+        elif N == 1:
             a(f"v_add_f32 v{ACC0}, v{g}, v{ACC0}")
         else:
             for j in range(N):
@@ -435,6 +447,11 @@ def main():
             for line in body_lds(N, KMAX):
                 out.write(f'  "{line}\\n" \\\n')
             out.write('  ""\n')
+    for KMAX in (160, 192):
+        out.write(f"#define PP_REGACC_LDS_BODY_N2PK_K{KMAX} \\\n")
+        for line in body_lds(2, KMAX, PK=True):
+            out.write(f'  "{line}\\n" \\\n')
+        out.write('  ""\n')
     for KMAX in (160, 192):
         out.write(f"#define PP_REGACC_LDS1_BODY_K{KMAX} \\\n")
         for line in body_lds1(KMAX):
