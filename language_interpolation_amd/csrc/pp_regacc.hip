@@ -439,13 +439,14 @@ bool pp_regacc_supported(const PPShape& sh) {
 // Where it measured fastest (profiles/r02_e_layer_bench.txt): every supported shape, except the
 // very small ones where a few million float atomics are cheaper than its three launches.  In
 // parts (K > 192) every wave walks all rows for the table rows of its part: still ahead of the
-// sort at every batch the row-owner kernel does not take (cfg4 input 16 -> 1000, K = 256: 35 vs
-// 50 us at 1000 rows, 124 vs 209 at 16384; 200 -> 200 with K = 300: 48 vs 146 and 394 vs 531;
-// profiles/r03_e_regacc_lds.txt).
+// sort at every batch (cfg4 input 16 -> 1000, K = 256: 35 vs 50 us at 1000 rows, 110 vs 209 at
+// 16384; 200 -> 200 with K = 300: 48 vs 146 and 332 vs 531), and of the row-owner kernel except
+// on few-input layers up to 512 rows (16 -> 1000: 19.2 vs 17.8 us at 256 rows, 32 vs 28 at 512;
+// 200 -> 200, K = 300: 27 vs 36 and 34 vs 67; profiles/r03_e_regacc_lds.txt).
 bool pp_regacc_preferred(const PPShape& sh) {
   if (!pp_regacc_supported(sh)) return false;
-  if (pp_regacc_parts(sh) > 1) return sh.B > 512;
-  return (long)sh.B * sh.I * sh.n * sh.O >= 2500000L;
+  if ((long)sh.B * sh.I * sh.n * sh.O < 2500000L) return false;
+  return pp_regacc_parts(sh) == 1 || sh.B > 512 || sh.I > 32;  // (else PP_BWD_W_DIRECT, pp_api.hip)
 }
 
 size_t pp_regacc_workspace_bytes(const PPShape& sh) { return make_plan(sh).bytes; }

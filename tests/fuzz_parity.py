@@ -50,7 +50,7 @@ def draw_case(rng: random.Random, large: bool = False):
             return disc, n, S, I, O, B, rng.choice(DISTS), rng.randrange(1 << 30)
 
 
-FWD = ["gather", "dense", "bf16x3", "fp16x2", "slab"]
+FWD = ["gather", "dense", "bf16x3", "fp16x2", "slab", "tile"]
 BWD_X = ["gather", "dense", "bf16x3", "fp16x2"]
 BWD_W = ["atomic", "sort", "dense", "bf16x3", "fp16x2", "regacc", "direct"]
 
@@ -222,6 +222,14 @@ def run_fused(case):
         ref = {"gx": x32.grad if x32.grad is not None else torch.zeros_like(x32), "gw": w64.grad}
         g_raw = raw.grad.detach()
         raw, yo = raw.detach(), yo.detach()
+        # max-abs: the gradient branches on the arg-max of the row.  Rows whose two largest
+        # |outputs| agree to within the bar have no arg-max an fp32 evaluation can decide (seed
+        # 11, round 3: 0.8129.. twice in one row, 6e-8 apart); gx is judged without those rows,
+        # and a gw they contribute to counts as ill-conditioned.
+        ties = torch.zeros(B, dtype=torch.bool)
+        if name == "max_abs" and O >= 2:
+            top = raw.abs().topk(2, dim=1).values
+            ties = (top[:, 0] - top[:, 1]) <= 1e-5 * top[:, 0]
         scache = {}
 
         def sums():
@@ -258,7 +266,12 @@ def run_fused(case):
                 e32 = rel_err(ref32()[key], ref[key])
                 msg = (f"{name}: {key} ({which}) vs the fp64 oracle of the pair {e:.3e} "
                        f"(fp32 reference: {e32:.3e}; max|ref| / max sum|terms| = {cancel:.2e})")
-                (soft if (e <= 2 * e32 or e * cancel <= 5e-5) else bad).append(msg)
+                tied = False
+                if ties.any():
+                    msg += f"; {int(ties.sum())} row(s) with an undecidable arg-max"
+                    tied = key == "gw" or bool((~ties).any() and rel_err(
+                        got[~ties], ref[key][~ties]) <= 5e-5) or not (~ties).any()
+                (soft if (tied or e <= 2 * e32 or e * cancel <= 5e-5) else bad).append(msg)
         # (rows whose layer output is almost constant, or almost zero, amplify the layer's own
         # rounding: the bar is the network test's 5 * TOL, rows with a tiny spread left out)
         spread = raw.std(dim=1) if name == "layer_norm" else raw.abs().amax(dim=1)
