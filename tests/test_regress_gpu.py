@@ -220,7 +220,10 @@ def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
     K = n * S if disc else (n - 1) * S + 1
     want = _lib.BWD_W_REGACC if B * I * n * O >= 2500000 else _lib.BWD_W_ATOMIC
     if K > 192:
-        want = _lib.BWD_W_REGACC if (B > 512 or I > 32) and B * I * n * O >= 2500000 else _lib.BWD_W_DIRECT
+        if (B > 512 or I > 32) and B * I * n * O >= 2500000:
+            want = _lib.BWD_W_REGACC
+        else:
+            want = _lib.BWD_W_DIRECT if B <= 512 else _lib.BWD_W_SORT
     assert lib.pp_auto_method(2, B, I, O, n, S, int(disc), 2.0) == want, "planner"
     PF = _pf()
     x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=90 + n)
