@@ -133,6 +133,12 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __rest
   const int b0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
   {
     const int col = t & 31, rp = t >> 5;
+    float xr[8];  // all eight loads before the first use (a chain of 8 round trips otherwise)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int b = b0 + rr * 8 + rp, i = i0 + col;
+      xr[rr] = (b < sh.B && i < sh.I) ? x[(size_t)b * sh.I + i] : 0.0f;
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int rl = rr * 8 + rp;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < N; ++j) l[j] = 0.0f;
       if (b < sh.B && i < sh.I) {
-        const float xv = x[(size_t)b * sh.I + i];
+        const float xv = xr[rr];
         const int s = pp_segment(xv, sh.length, sh.half, sh.Sf, sh.S);
         if constexpr (N > 1) {
           const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);

@@ -49,6 +49,24 @@ RB = 16
 SC0 = 36     # scalars of the current block
 
 
+def write_out(a, KMAX, ACC0, voff):
+    """Row k of the table = accumulator k, lanes with an out only.  Unrolled over the registers
+    (round 3): the first version walked them with the index mode (on / v_mul / off / store per
+    row), ~13 us of fixed cost in a launch at the reference's batch sizes."""
+    a("v_cmp_ne_u32 vcc, 0, %[vok]")
+    a("s_and_b64 exec, exec, vcc")
+    a("s_cbranch_execz 4f")
+    for k in range(KMAX):
+        a(f"s_cmp_le_u32 %[K], {k}")
+        a("s_cbranch_scc1 4f")
+        a(f"v_mul_f32 v{ACC0 + k}, %[scale], v{ACC0 + k}")
+        a(f"global_store_dword v{voff}, v{ACC0 + k}, s[28:29]")
+        a("s_add_u32 s28, s28, %[rowb]")
+        a("s_addc_u32 s29, s29, 0")
+    a("4:")
+    a("s_mov_b64 exec, -1")
+
+
 def body(N, KMAX):
     P = 1 if N == 1 else 1 + N
     ACC0 = 256 - KMAX
@@ -133,21 +151,7 @@ def body(N, KMAX):
             a("s_cbranch_scc0 1b")
     a("2:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    # ---- write-out: row k of the table = accumulator k, lanes with an out only
-    a("v_cmp_ne_u32 vcc, 0, %[vok]")
-    a("s_and_b64 exec, exec, vcc")
-    a("s_mov_b32 s35, 0")
-    a("3:")
-    a("s_set_gpr_idx_on s35, gpr_idx(SRC1)")
-    a(f"v_mul_f32 v{STG0}, %[scale], v{ACC0}")
-    a("s_set_gpr_idx_off")
-    a(f"global_store_dword v{VOFF0}, v{STG0}, s[28:29]")
-    a("s_add_u32 s28, s28, %[rowb]")
-    a("s_addc_u32 s29, s29, 0")
-    a("s_add_u32 s35, s35, 1")
-    a("s_cmp_lt_u32 s35, %[K]")
-    a("s_cbranch_scc1 3b")
-    a("s_mov_b64 exec, -1")
+    write_out(a, KMAX, ACC0, VOFF0)
     return L
 
 
@@ -286,21 +290,7 @@ def body_lds(N, KMAX, PK=False):
             a("s_cbranch_scc0 1b")
     a("2:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    # ---- write-out: row k of the table = accumulator k, lanes with an out only
-    a("v_cmp_ne_u32 vcc, 0, %[vok]")
-    a("s_and_b64 exec, exec, vcc")
-    a("s_mov_b32 s35, 0")
-    a("3:")
-    a("s_set_gpr_idx_on s35, gpr_idx(SRC1)")
-    a(f"v_mul_f32 v{SA}, %[scale], v{ACC0}")
-    a("s_set_gpr_idx_off")
-    a(f"global_store_dword v16, v{SA}, s[28:29]")
-    a("s_add_u32 s28, s28, %[rowb]")
-    a("s_addc_u32 s29, s29, 0")
-    a("s_add_u32 s35, s35, 1")
-    a("s_cmp_lt_u32 s35, %[K]")
-    a("s_cbranch_scc1 3b")
-    a("s_mov_b64 exec, -1")
+    write_out(a, KMAX, ACC0, 16)
     return L
 
 
@@ -415,20 +405,7 @@ def body_lds1(KMAX):
             a("s_cbranch_scc0 1b")
     a("2:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    a("v_cmp_ne_u32 vcc, 0, %[vok]")
-    a("s_and_b64 exec, exec, vcc")
-    a("s_mov_b32 s35, 0")
-    a("3:")
-    a("s_set_gpr_idx_on s35, gpr_idx(SRC1)")
-    a(f"v_mul_f32 v{SA}, %[scale], v{ACC0}")
-    a("s_set_gpr_idx_off")
-    a(f"global_store_dword v16, v{SA}, s[28:29]")
-    a("s_add_u32 s28, s28, %[rowb]")
-    a("s_addc_u32 s29, s29, 0")
-    a("s_add_u32 s35, s35, 1")
-    a("s_cmp_lt_u32 s35, %[K]")
-    a("s_cbranch_scc1 3b")
-    a("s_mov_b64 exec, -1")
+    write_out(a, KMAX, ACC0, 16)
     return L
 
 

@@ -13,6 +13,8 @@ from language_interpolation_amd import functional as PF  # noqa: E402
 
 SHAPES = [(True, 1, 150, 200, 200, 16384), (False, 2, 128, 16, 250, 16384), (True, 2, 64, 16, 1000, 16384),
           (True, 2, 128, 16, 1000, 16384), (True, 2, 150, 200, 200, 16384)]
+if os.environ.get("REGACC_B"):
+    SHAPES = [s[:5] + (int(os.environ["REGACC_B"]),) for s in SHAPES]
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(1)
 for disc, n, S, I, O, B in SHAPES:
