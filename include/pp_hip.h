@@ -94,7 +94,9 @@ enum {
   PP_BWD_W_REGACC = 6, /* many segments (weight rows per input K <= 192, n <= 3): a wave owns one input
                           x 64 outs, keeps one register per weight row and adds the batch rows in
                           their natural order through the VGPR index mode; no sort, no zero fill, no
-                          atomics, bitwise reproducible; needs a workspace */
+                          atomics, bitwise reproducible; needs a workspace.  Discontinuous layers
+                          with n = 2, 3 up to K <= 576: two or three waves an input, whole segments
+                          each.  Large layers x batches share gy through LDS (round 3) */
   PP_BWD_W_DIRECT = 7, /* small batches (B <= 1024, n <= 4) of many-segment layers: the wave that owns a
                           weight row finds the batch rows that land on it (segment ids of the input
                           column in LDS, ballots in row order) and stores the finished row once; no
