@@ -80,10 +80,12 @@ RegaccPlan make_plan(const PPShape& sh) {
   const int IV = sh.I * p.H;
   p.nquad = (IV + 3) / 4;
   const long waves_full = (long)IV * p.nchunk;
-  // gy through LDS where there is enough work to fill the chip with its 4-wave workgroups
-  // (tools/regacc_sweep.py, profiles/r03_e_regacc_lds.txt: 201 -> 121 us on the cfg3 hidden layer
-  // at 16384 rows, 63 -> 51 at 4096, even at 2048; behind for few inputs or small batches)
-  p.lds = (long)sh.B * p.nquad * p.nchunk >= 500000L;
+  // gy through LDS (tools/regacc_sweep.py, profiles/r03_e_regacc_lds.txt): n = 1 from 512 rows
+  // (byte records, index mode on for 64 rows: 213 -> 111 us on the cfg3 hidden layer at 16384
+  // rows, 24.9 -> 21.3 at 1000); n >= 2 where rows x workgroups-per-slice >= 250 k (16 -> 1000
+  // with K = 128: 94 -> 82 us at 16384 rows, level at 2048; behind on the 16-input layers from
+  // 1000 to 4096 rows, 25-31 vs 22-27 us)
+  p.lds = sh.n == 1 ? sh.B >= 512 : (long)sh.B * p.nquad * p.nchunk >= 250000L;
 #ifdef PP_TUNING  // developer builds only
   if (const char* e = getenv("PP_REGACC_LDS")) p.lds = atoi(e) != 0;
 #endif
@@ -91,7 +93,10 @@ RegaccPlan make_plan(const PPShape& sh) {
   if (p.lds) {
     // two workgroups a CU (256 registers a wave): 512 resident at a time; one alone on a CU
     // idles at its barriers (212 us unsliced on the cfg3 hidden layer, 106 + 12 in two slices)
-    ns = std::max<long>(1, 512 / ((long)p.nquad * p.nchunk));
+    // ... and at least 1024 rows a slice: below that the per-workgroup fixed work and the
+    // slice sum grow faster than the loop shrinks (16 -> 250 at 16384 rows: 37.8 us in 16
+    // slices, 47 in 32; tools/regacc_ns.py)
+    ns = std::max<long>(1, std::min<long>(512 / ((long)p.nquad * p.nchunk), p.nsb / 16));
   } else if (waves_full < 768) {
     ns = (1024 + waves_full - 1) / waves_full;
   }

@@ -199,7 +199,8 @@ REGACC_CASES = [
     (True, 3, 64, 5, 64, 129, "normal", 2.0),           # K = 192: the shallow register layout
     (True, 1, 192, 3, 1, 17, "uniform", 1.0),           # one out, less than one block of rows
     (False, 2, 191, 9, 130, 2049, "normal", 1.0),       # K = 192 continuous
-    # gy through LDS (batch x workgroups-per-slice >= 500 k; the first case above too):
+    # gy through LDS (n = 1 from 512 rows -- the first two cases above --, n >= 2 where batch x
+    # workgroups-per-slice >= 250 k -- the third and fifth above too):
     (True, 1, 192, 130, 260, 3107, "normal", 1.0),      # byte records, K = 192, two waves without an input, 4-out tail
     (True, 2, 64, 16, 1000, 16379, "char", 0.5),        # n = 2, eight slices, ragged rows
     (True, 3, 64, 66, 250, 7501, "edges", 1.0),         # n = 3, K = 192, rows of 1000 bytes (8-byte aligned only)

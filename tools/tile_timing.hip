@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
   int I = 200, O = 200, n = 1, S = 150, disc = 1;
   if (!strcmp(which, "cfg4")) { I = 16; O = 1000; n = 2; S = 128; }
   if (!strcmp(which, "cfg1")) { I = 16; O = 200; n = 2; S = 128; disc = 0; }
+  if (!strcmp(which, "cfg2")) { I = 16; O = 250; n = 2; S = 128; disc = 0; }
   PPShape sh;
   sh.B = B; sh.I = I; sh.O = O; sh.n = n; sh.S = S;
   sh.K = disc ? n * S : (n - 1) * S + 1;
