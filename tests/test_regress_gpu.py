@@ -249,6 +249,51 @@ def test_regacc_weight_gradient_matches_oracle_and_is_reproducible(case):
     assert rel_err(gw_tail.cpu(), want_gw) <= 4 * TOL
 
 
+# (disc, n, S, I, O, B): BASELINE's many-segment layers at the bench batch and four times it, far
+# beyond what the oracle can expand
+FULL_SIZE_GW = [
+    (True, 1, 150, 200, 200, 16384),    # cfg3 hidden: byte records, gy through LDS, two slices
+    (True, 1, 150, 200, 128, 65536),    # cfg3 output layer at 65536 rows
+    (True, 2, 128, 16, 1000, 16384),    # cfg4 input: K = 256 in two parts, packed FMA
+    (True, 2, 128, 16, 1000, 65536),
+    (True, 2, 150, 200, 200, 16384),    # cfg3 with the n_hidden quirk: K = 300
+    (False, 2, 128, 16, 250, 65536),    # cfg2 input layer
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_GW, ids=lambda c: "-".join(str(v) for v in c))
+def test_weight_gradient_sums_to_the_column_sums_of_gy_at_full_size(case):
+    """Size-independent property: the basis of a row sums to one (partition of unity), so the
+    table of every input i sums over its K rows to the column sums of gy,
+    sum_k gw_t[i, k, o] = sum_b gy[b, o] -- whatever x is (for n = 1 non-finite values included).
+    Plus the same bits on a second launch and agreement with the sorted path."""
+    disc, n, S, I, O, B = case
+    PF = _pf()
+    K = n * S if disc else (n - 1) * S + 1
+    # (n >= 2: inputs inside the grid -- far outside it the basis values are large and of both
+    # signs, and their sum is 1 only up to that cancellation)
+    dist = "char" if I == 16 else ("normal" if n == 1 else "uniform")
+    x, _, gy = make_inputs(B, I, 8, n, S, disc, dist, seed=77)   # (w is not needed: 8 outs of it)
+    gen = torch.Generator().manual_seed(78)
+    gy = torch.randn(B, O, generator=gen)
+    if n == 1:   # the basis is 1 wherever x is; for n >= 2 stay where l_0 + .. + l_{n-1} = 1 holds in fp32
+        x[5, 0], x[6, 1], x[7, 2] = float("inf"), float("-inf"), 3.0e30
+    else:
+        x[5, 0], x[6, 1], x[7, 2] = 1.3, -1.7, 1.0
+    xd, gyd = x.cuda(), gy.cuda()
+    spec = PF.make_spec(n, S, disc, in_features=I)      # the planner's choice
+    gw = PF.backward_weight_raw(xd, gyd, (I, K, O), spec)
+    assert torch.equal(PF.backward_weight_raw(xd, gyd, (I, K, O), spec), gw)
+    col = gyd.double().sum(dim=0)                       # [O]
+    scale = gyd.double().abs().sum(dim=0).max().item()  # what a rounding error is relative to
+    got = gw.double().sum(dim=1)                        # [I, O]
+    assert float((got - col).abs().max()) <= 2e-6 * scale
+    if K <= 1024:
+        gs = PF.backward_weight_raw(xd, gyd, (I, K, O),
+                                    PF.make_spec(n, S, disc, bwd_w_method="sort", in_features=I))
+        assert rel_err(gw, gs) <= TOL
+
+
 # (disc, n, S, I, O, B, dist, out_scale): the small-batch weight gradient (PP_BWD_W_DIRECT)
 DIRECT_CASES = [
     (True, 2, 128, 16, 1000, 256, "char", 1.0),         # cfg4 input layer at the reference's batch
