@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int kMaxRows = 1024;  // batch rows whose ids fit the block's LDS
-constexpr int kKB = 16;         // weight rows per block
+constexpr int kKB = 8;          // weight rows per block (16: 17.8 us on the cfg4 input layer at 256 rows, 8: 16.2, 4: 16.6)
 constexpr int kDU = 8;          // gy rows requested before the first is used
 
 template <int N, int V>

@@ -12,6 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from language_interpolation_amd import _lib  # noqa: E402
+
+if os.environ.get("PP_LIB"):  # a developer build of the library
+    _lib.LIB_PATH = os.environ["PP_LIB"]
 from language_interpolation_amd import functional as PF  # noqa: E402
 
 # name: (disc, n, I, O, S, xdist, first_layer)
