@@ -12,7 +12,11 @@ name = sys.argv[3] if len(sys.argv) > 3 else "cfg2_hidden"
 disc, n, I, O, S, dist, first = LAYERS[name]
 K = PF.num_weights(n, S, disc)
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, I, generator=g).cuda()
+if dist == "char":  # first layers: character windows drawn from the reference text's histogram
+    from bench import char_batch
+    x = char_batch(B, I, g).cuda()
+else:
+    x = torch.randn(B, I, generator=g).cuda()
 w_t = ((torch.rand(I, K, O, generator=g) * 2 - 1) / I).cuda()
 gy = (torch.randn(B, O, generator=g) / O).cuda()
 spec = PF.make_spec(n, S, disc)
