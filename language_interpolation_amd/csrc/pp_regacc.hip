@@ -106,10 +106,21 @@ RegaccPlan make_plan(const PPShape& sh) {
 #ifdef PP_TUNING  // developer builds only
   if (const char* e = getenv("PP_REGACC_NSLICE")) ns = std::max(1, atoi(e));
 #endif
-  p.sbps = (int)((p.nsb + ns - 1) / ns);
   p.packed = p.lds && sh.n == 1;
-  if (p.packed) p.sbps = (p.sbps + 3) & ~3;  // slices start on a group of 256 rows
-  p.nslice = (p.nsb + p.sbps - 1) / p.sbps;
+  auto slices = [&](long want) {
+    p.sbps = (int)((p.nsb + want - 1) / want);
+    if (p.packed) p.sbps = (p.sbps + 3) & ~3;  // slices start on a group of 256 rows
+    p.nslice = (p.nsb + p.sbps - 1) / p.sbps;
+  };
+  // (chunk, slice) pairs a multiple of 8 where a nearby slice count gives that: regacc_block
+  slices(ns);
+  if ((p.nchunk * p.nslice) % 8 != 0) {
+    for (long want = ns - 1; want >= 1 && 2 * want > ns; --want) {
+      slices(want);
+      if ((p.nchunk * p.nslice) % 8 == 0) break;
+    }
+    if ((p.nchunk * p.nslice) % 8 != 0) slices(ns);
+  }
   p.rec_ints_per_input = p.packed
                              ? (size_t)((p.nsb + 3) / 4 + 1) * 64  // a byte a row, one group of slack
                              : (size_t)(p.nsb + 1) * planes_of(sh.n) * kSB;  // one super-block of slack
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void pp_regacc_prep_packed_kernel(const float*
 }
 
 struct RegaccArgs {
-  int B, I, O, K, nchunk, nquad, sbps, nblk, H, KH;
+  int B, I, O, K, nchunk, nquad, sbps, nblk, H, KH, xcd;
   size_t rec_ints_per_input;
   size_t slice_stride;  // floats between the tables of two slices
   float scale;
@@ -256,6 +267,28 @@ struct RegaccArgs {
                  [lane4] "v"(lane4), [ldsr] "v"(ldsr), [dma0] "v"(dma0)                           \
                : PP_REGACC_CLOBBERS)
 
+// Which (group of 4 inputs, out chunk, row slice) a workgroup takes.  Workgroups are handed to the
+// 8 XCDs round-robin by block id, each XCD has its own L2, and all nquad workgroups of one (chunk,
+// slice) read the same piece of gy: with the plain numbering they land on all 8 XCDs and every
+// one of them fetches that piece from HBM again (PMC, cfg4 input at 16384 rows: 262 k KB fetched
+// per launch for a 65 MB gy).  When the number of (chunk, slice) pairs is a multiple of 8 the
+// pair is picked by the XCD (block id % 8) and the quads of a pair follow each other on it.
+__device__ __forceinline__ void regacc_block(const RegaccArgs& a, int& q, int& c, int& slice) {
+  int bid = blockIdx.x;
+  if (a.xcd) {
+    const int x = bid & 7, t = bid >> 3;
+    q = t % a.nquad;
+    const int pair = (t / a.nquad) * 8 + x;
+    c = pair % a.nchunk;
+    slice = pair / a.nchunk;
+  } else {
+    q = bid % a.nquad;
+    bid /= a.nquad;
+    c = bid % a.nchunk;
+    slice = bid / a.nchunk;
+  }
+}
+
 // DEEP: the variant for K <= PP_REGACC_KDEEP (64 staging registers: gy loads run 3 blocks ahead).
 template <int N, bool DEEP>
 __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* __restrict__ gy,
@@ -265,11 +298,8 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_kernel(const float* 
   constexpr int P = planes_of(N);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  int bid = blockIdx.x;
-  const int q = bid % a.nquad;
-  bid /= a.nquad;
-  const int c = bid % a.nchunk;
-  const int slice = bid / a.nchunk;
+  int q, c, slice;
+  regacc_block(a, q, c, slice);
   const int iv = q * 4 + wave;  // input i, part h of its table rows
   if (iv >= a.I * a.H) return;  // whole wave
   const int i = iv / a.H, h = iv - i * a.H;
@@ -320,11 +350,8 @@ __global__ __launch_bounds__(256) void pp_bwd_weight_regacc_lds_kernel(const flo
   __shared__ __attribute__((aligned(1024))) float stage[2 * kSB * 64];  // two blocks of 64 rows x 64 outs
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  int bid = blockIdx.x;
-  const int q = bid % a.nquad;
-  bid /= a.nquad;
-  const int c = bid % a.nchunk;
-  const int slice = bid / a.nchunk;
+  int q, c, slice;
+  regacc_block(a, q, c, slice);
   const bool own = q * 4 + wave < a.I * a.H;
   const int iv = own ? q * 4 + wave : a.I * a.H - 1;  // input i, part h of its table rows
   const int i = iv / a.H, h = iv - i * a.H;
@@ -393,6 +420,10 @@ hipError_t launch(const float* x, const float* gy, float* gwt, void* ws, const P
   a.B = sh.B; a.I = sh.I; a.O = sh.O; a.K = sh.K;
   a.nchunk = p.nchunk; a.nquad = p.nquad; a.sbps = p.sbps; a.nblk = p.nblk;
   a.H = p.H; a.KH = p.KH;
+  a.xcd = (p.nchunk * p.nslice) % 8 == 0;
+#ifdef PP_TUNING  // developer builds only
+  if (const char* e = getenv("PP_REGACC_XCD")) a.xcd = a.xcd && atoi(e) != 0;
+#endif
   a.rec_ints_per_input = p.rec_ints_per_input;
   a.slice_stride = (size_t)sh.I * sh.K * sh.O;
   a.scale = p.nslice > 1 ? 1.0f : sh.out_scale;
