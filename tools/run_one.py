@@ -3,6 +3,9 @@ python tools/run_one.py <pass: fwd|bwd_x|bwd_w> [B] [layer name from layer_bench
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from language_interpolation_amd import _lib
+if os.environ.get("PP_LIB"):
+    _lib.LIB_PATH = os.environ["PP_LIB"]
 from language_interpolation_amd import functional as PF
 from tools.layer_bench import LAYERS
 
