@@ -268,13 +268,20 @@ int pp_max_abs_norm_bwd_f32(const float* x, const float* gy, float* gx, int B, i
  * pp_max_abs_norm_bwd_y_f32 is the backward from those and the NORMALISED row:
  *   gx_j = (gy_j - [j == amax] * sign(y_amax) * sum_k gy_k y_k) / den.
  * n <= 4, 4 <= O <= 1024.  pp_forward_max_abs_supported: 2 when this is what a caller should run
- * for the shape (a layer the gather kernels serve), else 0 -- the matrix-core forward has no
- * max-abs epilogue (no configuration of the reference's README uses this normalisation). */
+ * for the shape (a layer the gather kernels serve), 1 for the layers of the dense regime, which
+ * have the same epilogue in the fp16x2 matrix-core kernel (round 3; O <= 256, a block holds whole
+ * rows): pp_forward_max_abs_ws_f32 with `packed` = the weights pre-split by pp_pack_weights_f32
+ * (bit-identical to pp_forward_ws_f32(PP_FWD_FP16X2) + pp_max_abs_norm_fwd_f32; packed == NULL is
+ * pp_forward_max_abs_f32).  0: neither. */
 int pp_forward_max_abs_supported(int B, int I, int O, int n, int S, int discontinuous,
                                  float length);
 int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,
                            int B, int I, int O, int n, int S, int discontinuous, float length,
                            const float* nodes, float out_scale, float eps, void* stream);
+int pp_forward_max_abs_ws_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,
+                              void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
+                              int discontinuous, float length, const float* nodes, float out_scale,
+                              float eps, void* stream);
 int pp_max_abs_norm_bwd_y_f32(const float* y, const float* gy, const float* den,
                               const int32_t* amax, float* gx, int B, int D, void* stream);
 

@@ -95,6 +95,8 @@ SIGNATURES = {
     "pp_max_abs_norm_bwd_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P]),
     "pp_forward_max_abs_supported": (c_int, [c_int] * 6 + [c_float]),
     "pp_forward_max_abs_f32": (c_int, [_P] * 5 + [c_int] * 6 + [c_float, _P, c_float, c_float, _P]),
+    "pp_forward_max_abs_ws_f32": (c_int, [_P] * 6 + [c_size_t] + [c_int] * 6 +
+                                  [c_float, _P, c_float, c_float, _P]),
     "pp_max_abs_norm_bwd_y_f32": (c_int, [_P] * 5 + [c_int, c_int, _P]),
     "pp_char_windows": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P, _P]),
     "pp_cross_entropy_workspace_bytes": (c_size_t, []),

@@ -245,7 +245,7 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
   if (method == (PP_FWD_FP16X2 | PP_WS_PREPACKED)) {
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
-    return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, true, nullptr, 0.0f,
+    return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, true, nullptr, 0.0f, nullptr,
                                    (hipStream_t)stream));
   }
   if (method == PP_METHOD_AUTO) {
@@ -275,7 +275,7 @@ int pp_forward_ws_f32(const float* x, const float* w_t, float* y, int32_t* seg_o
     if (!pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_fwd_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
     if (method == PP_FWD_FP16X2)
-      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, false, nullptr, 0.0f,
+      return hip_rc(pp_launch_fwd_h2(x, w_t, y, seg_out, workspace, sh, tab, false, nullptr, 0.0f, nullptr,
                                      st));
     return hip_rc(pp_launch_fwd_bf3(x, w_t, y, seg_out, workspace, sh, tab, st));
   }
@@ -492,7 +492,7 @@ int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float*
   if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
   BasisTab tab;
   make_basis(tab, n, length, nodes);
-  return hip_rc(pp_launch_fwd_h2(x, w_t, y, nullptr, packed, sh, tab, true, rstd, eps,
+  return hip_rc(pp_launch_fwd_h2(x, w_t, y, nullptr, packed, sh, tab, true, rstd, eps, nullptr,
                                  (hipStream_t)stream));
 }
 
@@ -532,11 +532,32 @@ int pp_forward_max_abs_f32(const float* x, const float* w_t, float* y, float* de
                                             (hipStream_t)stream));
 }
 
+int pp_forward_max_abs_ws_f32(const float* x, const float* w_t, float* y, float* den, int32_t* amax,
+                              void* packed, size_t packed_bytes, int B, int I, int O, int n, int S,
+                              int discontinuous, float length, const float* nodes, float out_scale,
+                              float eps, void* stream) {
+  if (!packed)
+    return pp_forward_max_abs_f32(x, w_t, y, den, amax, B, I, O, n, S, discontinuous, length, nodes,
+                                  out_scale, eps, stream);
+  if (!x || !w_t || !y || !den || !amax) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(w_t) || !aligned16(y) || !aligned16(packed)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (!pp_h2_fwd_ln_supported(sh) || !pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
+  if (packed_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_fwd_h2(x, w_t, y, nullptr, packed, sh, tab, true, den, eps, amax,
+                                 (hipStream_t)stream));
+}
+
 int pp_forward_max_abs_supported(int B, int I, int O, int n, int S, int discontinuous,
                                  float length) {
   PPShape sh;
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
-  // the gather kernels' layers only: the matrix-core forward has no max-abs epilogue
+  // 1: the fp16x2 matrix-core kernel (whole rows per block, O <= 256), 2: the gather kernel
+  if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && matrix_core_fwd(sh)) return 1;
   return (!matrix_core_fwd(sh) && pp_gather_ln_supported(sh)) ? 2 : 0;
 }
 

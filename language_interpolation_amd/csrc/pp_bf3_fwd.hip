@@ -66,9 +66,13 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
                                                              float* __restrict__ y, PPShape sh,
                                                              BasisTab tab, DenseCoord3 dc,
                                                              int nstep, float* __restrict__ rstd_out,
-                                                             float ln_eps) {
+                                                             float ln_eps,
+                                                             int32_t* __restrict__ amax_out) {
   // rstd_out != nullptr: y is the non-affine LayerNorm of the layer's output over the row
   // (LazyLayerNormLastDim fused into the epilogue) and rstd_out[B] its 1/std.
+  // amax_out != nullptr as well: y is MaxAbsNormalizationLast of the row instead, rstd_out[B]
+  // receives the denominators max|row| + ln_eps and amax_out[B] the first index attaining the
+  // maximum (what pp_max_abs_norm_bwd_y_f32 works from).
   // block = G groups of 4 waves.  A group = 4 column tiles (32*NT outs each) x one tile
   // of 32*RM rows; every W fragment a wave loads feeds RM row tiles.  With G = 2 the two
   // groups take alternate 16-input steps of the SAME output tile (split-k inside the
@@ -295,7 +299,79 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
       }
     });
     PP_TICK(4)
-    if (rstd_out) {
+    if (amax_out) {
+      // fused MaxAbsNormalizationLast over the row (the block holds whole rows: grid.y == 1).
+      // The maximum of a set does not depend on the order it is taken in and the division is
+      // the correctly rounded one: bit-identical to this kernel + pp_max_abs_fwd_kernel.
+      float* mL = statL + 8 * G * ROWS;
+      int* iL = reinterpret_cast<int*>(statL);
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rr = rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          float m = 0.0f;
+          static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            if (kept(rm * NT + nt)) {  // (folds after unrolling)
+              if (o0 + nt * 32 + r < sh.O) m = fmaxf(m, fabsf(acc[rm][nt][q]));
+            }
+          });
+          m = pp_dpp_max<0x128>(m);
+          m = pp_dpp_max<0x124>(m);
+          m = pp_dpp_max<0x122>(m);
+          m = pp_dpp_max<0x121>(m);
+          if ((r & 15) == 0) statL[(wv * 2 + (r >> 4)) * ROWS + rr] = m;
+        }
+      __syncthreads();
+      if (threadIdx.x < ROWS) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8 * G; ++w) tot = fmaxf(tot, statL[w * ROWS + threadIdx.x]);
+        mL[threadIdx.x] = tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rr = rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const float m = mL[rr];
+          int idx = 0x7fffffff;  // first index attaining the maximum
+          static_for<NT>([&](auto nc) {
+            constexpr int nt = decltype(nc)::value;
+            if (kept(rm * NT + nt)) {
+              const int col = o0 + nt * 32 + r;
+              if (col < sh.O && fabsf(acc[rm][nt][q]) == m) idx = min(idx, col);
+            }
+          });
+          idx = pp_dpp_min_i<0x128>(idx);
+          idx = pp_dpp_min_i<0x124>(idx);
+          idx = pp_dpp_min_i<0x122>(idx);
+          idx = pp_dpp_min_i<0x121>(idx);
+          if ((r & 15) == 0) iL[(wv * 2 + (r >> 4)) * ROWS + rr] = idx;
+        }
+      __syncthreads();
+      if (threadIdx.x < ROWS) {
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < 8 * G; ++w) best = min(best, iL[w * ROWS + threadIdx.x]);
+        if (b0 + (int)threadIdx.x < sh.B) {
+          amax_out[b0 + threadIdx.x] = best;
+          rstd_out[b0 + threadIdx.x] = mL[threadIdx.x] + ln_eps;
+        }
+      }
+      static_for<NTILE>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr (kept(T)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rr = (T / NT) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            acc[T / NT][T % NT][q] = acc[T / NT][T % NT][q] / (mL[rr] + ln_eps);
+          }
+        }
+      });
+    } else if (rstd_out) {
       // fused non-affine LayerNorm over the row (the block holds whole rows: grid.y == 1):
       // two passes (mean, then centred second moment), partial row sums per wave in LDS
       float* meanL = statL + 8 * G * ROWS;
@@ -375,7 +451,27 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
     if (bad) {
       fwd_tile_fp32<N, K>(x, wt, y, sh, tab, dc, b0, ROWS, blockIdx.y * 128 * NT,
                           min(sh.O, (int)(blockIdx.y + 1) * 128 * NT));
-      if (rstd_out) {  // ... and normalise its rows in place: wave w takes rows w, w+4G, ...
+      if (amax_out) {  // ... and normalise its rows in place: wave w takes rows w, w+4G, ...
+        __syncthreads();
+        for (int rr = wv; rr < ROWS && b0 + rr < sh.B; rr += 4 * G) {
+          float* yr = y + (size_t)(b0 + rr) * sh.O;
+          float m = 0.0f;
+          for (int c = lane; c < sh.O; c += 64) m = fmaxf(m, fabsf(yr[c]));
+#pragma unroll
+          for (int dd = 32; dd > 0; dd >>= 1) m = fmaxf(m, __shfl_xor(m, dd));
+          int idx = 0x7fffffff;
+          for (int c = lane; c < sh.O; c += 64)
+            if (fabsf(yr[c]) == m) idx = min(idx, c);
+#pragma unroll
+          for (int dd = 32; dd > 0; dd >>= 1) idx = min(idx, __shfl_xor(idx, dd));
+          const float den = m + ln_eps;
+          for (int c = lane; c < sh.O; c += 64) yr[c] = yr[c] / den;
+          if (lane == 0) {
+            rstd_out[b0 + rr] = den;
+            amax_out[b0 + rr] = idx;
+          }
+        }
+      } else if (rstd_out) {
         __syncthreads();
         for (int rr = wv; rr < ROWS && b0 + rr < sh.B; rr += 4 * G) {
           float* yr = y + (size_t)(b0 + rr) * sh.O;
@@ -403,7 +499,7 @@ int nstep_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 2; }
 template <class SC, int N, int K, int RM, int NT, int G>
 hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y, const PPShape& sh,
                       const BasisTab& tab, const DenseCoord3& dc, int nstep, float* rstd,
-                      float ln_eps, hipStream_t st) {
+                      float ln_eps, int32_t* amax, hipStream_t st) {
   size_t lds = (size_t)G * 2 * SC::PL * K * 2 * 32 * RM * 16;
   // epilogue: exchange area of the two groups + LayerNorm row statistics
   const size_t red = G == 2 ? (size_t)2 * 4 * std::max(1, RM * NT / 2) * 16 * 64 * 4 : 0;
@@ -417,7 +513,7 @@ hipError_t launch_bf3(const float* x, const float* wt, const void* ws, float* y,
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (sh.O + 128 * NT - 1) / (128 * NT));
   if (rstd && grid.y != 1) return hipErrorInvalidValue;  // the fused norm needs whole rows
   hipLaunchKernelGGL((pp_fwd_bf3_kernel<SC, N, K, RM, NT, G>), grid, dim3(256 * G), lds, st, x, wt,
-                     ws, y, sh, tab, dc, nstep, rstd, ln_eps);
+                     ws, y, sh, tab, dc, nstep, rstd, ln_eps, amax);
   return hipGetLastError();
 }
 
@@ -435,7 +531,7 @@ void pack_w_split(const float* wt, void* ws, const PPShape& sh, bool with_absmax
 template <class SC>
 hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                             const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
-                            float ln_eps, hipStream_t st) {
+                            float ln_eps, int32_t* amax, hipStream_t st) {
   const int nstep = nstep_of(sh);
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
@@ -464,12 +560,12 @@ hipError_t launch_fwd_split(const float* x, const float* wt, float* y, int32_t* 
     hipError_t e = hipErrorInvalidValue;                                                       \
     if constexpr (K_ <= 6) {                                                                   \
       if (rm == 2 && nt == 2)                                                                  \
-        e = launch_bf3<SC, N_, K_, 2, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st);             \
+        e = launch_bf3<SC, N_, K_, 2, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, amax, st);             \
       else if (rm == 2)                                                                        \
-        e = launch_bf3<SC, N_, K_, 2, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st);             \
+        e = launch_bf3<SC, N_, K_, 2, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, amax, st);             \
     }                                                                                          \
-    if (rm == 1 && nt == 2) e = launch_bf3<SC, N_, K_, 1, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st); \
-    else if (rm == 1) e = launch_bf3<SC, N_, K_, 1, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, st); \
+    if (rm == 1 && nt == 2) e = launch_bf3<SC, N_, K_, 1, 2, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, amax, st); \
+    else if (rm == 1) e = launch_bf3<SC, N_, K_, 1, 1, 2>(x, wt, ws, y, sh, tab, dc, nstep, rstd, ln_eps, amax, st); \
     if (e == hipSuccess && seg) e = pp_launch_segment_ids(x, seg, sh, st);                     \
     return e;                                                                                  \
   }
@@ -491,13 +587,13 @@ size_t pp_bf3_fwd_workspace_bytes(const PPShape& sh) {
 
 hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                              const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, false, nullptr, 0.0f, st);
+  return launch_fwd_split<SchemeBf3>(x, wt, y, seg, ws, sh, tab, false, nullptr, 0.0f, nullptr, st);
 }
 
 hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                             const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
-                            float ln_eps, hipStream_t st) {
-  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, prepacked, rstd, ln_eps, st);
+                            float ln_eps, int32_t* amax, hipStream_t st) {
+  return launch_fwd_split<SchemeH2>(x, wt, y, seg, ws, sh, tab, prepacked, rstd, ln_eps, amax, st);
 }
 
 // whole rows in one block: what the fused LayerNorm epilogue needs

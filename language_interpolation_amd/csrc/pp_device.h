@@ -155,6 +155,18 @@ __device__ __forceinline__ float pp_dpp_add(float v) {
   return v + __int_as_float(t);
 }
 
+// max / min with the value CTRL places away inside each row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ float pp_dpp_max(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __int_as_float(t));
+}
+template <int CTRL>
+__device__ __forceinline__ int pp_dpp_min_i(int v) {
+  const int t = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return min(v, t);
+}
+
 // Sum over the 64 lanes, returned in every lane: four row_ror DPP adds give each
 // lane its row's (16 lanes) sum; the four row sums are combined through SGPRs.
 // No LDS traffic (unlike __shfl_xor, which lowers to ds_bpermute).

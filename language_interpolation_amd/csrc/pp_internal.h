@@ -135,7 +135,7 @@ hipError_t pp_launch_fwd_bf3(const float* x, const float* wt, float* y, int32_t*
                              const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_fwd_h2(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                             const PPShape& sh, const BasisTab& tab, bool prepacked, float* rstd,
-                            float ln_eps, hipStream_t st);
+                            float ln_eps, int32_t* amax, hipStream_t st);  // amax: max-abs epilogue
 bool pp_h2_fwd_ln_supported(const PPShape& sh);
 size_t pp_h2_fwd_packed_bytes(const PPShape& sh);
 void pp_launch_pack_both_h2(const float* wt, void* ws, const PPShape& sh, hipStream_t st);

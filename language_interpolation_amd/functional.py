@@ -409,8 +409,8 @@ def piecewise_poly_layer_norm(x, w, spec: LayerSpec, eps: float = 1e-5) -> torch
 
 
 def max_abs_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> bool:
-    """True when `MaxAbsNormalizationLast(piecewise_poly(x, w))` has the fused kernel (the
-    layers the gather kernels serve) and the automatic method choice is in force."""
+    """True when `MaxAbsNormalizationLast(piecewise_poly(x, w))` has a fused kernel and the
+    automatic method choice is in force."""
     if spec.fwd_method != "auto" or spec.bwd_x_method != "auto" or x.dim() != 2 or \
             not x.is_cuda or x.shape[0] == 0:
         return False
@@ -420,8 +420,9 @@ def max_abs_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> bool:
 
 
 class PiecewisePolyMaxAbsFunction(torch.autograd.Function):
-    """y = MaxAbsNormalizationLast(piecewise_poly(x, w)) with the normalisation in the gather
-    kernel's epilogue.  Saves (x, w, y, den, amax); the backward is the max-abs backward from the
+    """y = MaxAbsNormalizationLast(piecewise_poly(x, w)) with the normalisation in the forward
+    kernel's epilogue (gather kernel, or the fp16x2 matrix-core kernel for dense-regime layers).
+    Saves (x, w, y, den, amax); the backward is the max-abs backward from the
     normalised row, then the layer's two backward kernels."""
 
     @staticmethod
@@ -433,16 +434,24 @@ class PiecewisePolyMaxAbsFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         B, I = x.shape
         O = w_t.shape[2]
+        mode = lib.pp_forward_max_abs_supported(B, I, O, spec.n, spec.segments,
+                                                int(spec.discontinuous), spec.length)
+        # mode 1: the fp16x2 matrix-core kernel on the pre-split weights (the backward-input's too)
+        packed = pack_weights(w_t, spec, B, version=w._version) if mode == 1 else None
+        if mode == 0 or (mode == 1 and packed is None):
+            raise _lib.PPHipError("fused layer+max-abs called on a layer that has no such kernel")
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)
         den = torch.empty(B, device=x.device, dtype=torch.float32)
         amax = torch.empty(B, device=x.device, dtype=torch.int32)
         with torch.cuda.device(x.device):
-            rc = lib.pp_forward_max_abs_f32(
-                _ptr(x), _ptr(w_t), _ptr(y), _ptr(den), _ptr(amax), B, I, O, spec.n, spec.segments,
+            rc = lib.pp_forward_max_abs_ws_f32(
+                _ptr(x), _ptr(w_t), _ptr(y), _ptr(den), _ptr(amax), _ptr(packed),
+                packed.numel() if packed is not None else 0, B, I, O, spec.n, spec.segments,
                 int(spec.discontinuous), spec.length, spec.node_array(), spec.out_scale, eps,
                 _stream(x.device))
-        _lib.check(rc, "pp_forward_max_abs_f32")
+        _lib.check(rc, "pp_forward_max_abs_ws_f32")
         ctx.spec = spec
+        ctx.packed = packed if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(x, w, y, den, amax)
         return y
 
@@ -463,7 +472,7 @@ class PiecewisePolyMaxAbsFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = backward_input_raw(x, g, w_t, spec)
+            gx = backward_input_raw(x, g, w_t, spec, packed=ctx.packed)
         if ctx.needs_input_grad[1]:
             gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
                                      out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)

@@ -119,8 +119,8 @@ class _Piecewise(nn.Module):
         return PF.piecewise_poly_layer_norm(self._prepare(x), self.w, self._spec, eps)
 
     def forward_max_abs(self, x: Tensor, eps: float = 1e-6):
-        """`MaxAbsNormalizationLast()(self(x))` in one kernel where the layer runs on the gather
-        kernels (None otherwise)."""
+        """`MaxAbsNormalizationLast()(self(x))` in one kernel where the layer has one (gather
+        kernels, fp16x2 matrix-core kernel up to 256 outs; None otherwise)."""
         if x.dim() != 2 or not PF.max_abs_fusable(x, self.w, self._spec):
             return None
         return PF.piecewise_poly_max_abs(self._prepare(x), self.w, self._spec, eps)

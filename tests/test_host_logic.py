@@ -100,10 +100,11 @@ def test_auto_method_selection():
     assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 4.0) == 2
     # fp16x2 layers with K >= 7 keep the fused LayerNorm up to 256 outs
     assert lib.pp_forward_layer_norm_supported(512, 64, 256, 4, 2, 0, 2.0) == 1
-    # the max-abs epilogue exists on the gather kernels only
+    # the max-abs epilogue: gather kernels (2) and the fp16x2 matrix-core kernel (1)
     assert lib.pp_forward_max_abs_supported(1000, 200, 200, 1, 150, 1, 2.0) == 2
     assert lib.pp_forward_max_abs_supported(256, 16, 1000, 2, 128, 1, 2.0) == 2
-    assert lib.pp_forward_max_abs_supported(512, 250, 250, 3, 2, 0, 2.0) == 0   # matrix-core layer
+    assert lib.pp_forward_max_abs_supported(512, 250, 250, 3, 2, 0, 2.0) == 1   # matrix-core layer
+    assert lib.pp_forward_max_abs_supported(512, 300, 300, 3, 2, 0, 2.0) == 0   # more than 256 outs
     assert lib.pp_forward_max_abs_supported(256, 16, 1030, 2, 128, 1, 2.0) == 0  # O > 1024
 
 

@@ -471,6 +471,99 @@ def test_high_order_mlp_with_max_abs_between_layers_fuses_on_the_gather_layers()
         assert rel_err(a.cpu(), b.cpu()) <= TOL
 
 
+# (B, I, O, n, S, disc): dense-regime layers the fp16x2 matrix-core forward serves (O <= 256)
+MATRIX_MAXABS_CASES = [
+    (16384, 250, 250, 3, 2, False),   # cfg2 hidden layer at the bench batch
+    (8300, 250, 128, 3, 2, False),    # cfg2 output layer: one wave group idle in the last tile
+    (1000, 200, 200, 2, 2, False),    # cfg1 hidden layer at the reference's batch
+    (513, 64, 128, 4, 2, False),      # n = 4, one row past a tile
+    (700, 40, 70, 2, 4, True),        # discontinuous, ragged outs
+]
+
+
+@pytest.mark.parametrize("shape", MATRIX_MAXABS_CASES, ids=lambda s: "-".join(str(v) for v in s))
+def test_matrix_core_forward_with_fused_max_abs(shape):
+    """layer -> MaxAbsNormalizationLast as one matrix-core kernel (mode 1 of
+    pp_forward_max_abs_supported): output, denominators and arg-max indices bit-identical to the
+    fp16x2 forward followed by the stand-alone normalisation (the maximum does not depend on the
+    order it is taken in, the division is the same instruction), gradients through
+    pp_max_abs_norm_bwd_y_f32 against the two-module path and the fp64 oracle of the pair."""
+    from language_interpolation_amd import _lib
+    from oracle import pp_oracle as po
+    PF = _pf()
+    B, I, O, n, S, disc = shape
+    lib = _lib.load()
+    assert lib.pp_forward_max_abs_supported(B, I, O, n, S, int(disc), 2.0) == 1
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=31)
+    spec = PF.make_spec(n, S, disc)
+    wd0 = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    res = []
+    for fn in (lambda a, b: PF.piecewise_poly_max_abs(a, b, spec, 1e-6),
+               lambda a, b: PF.max_abs_norm_last(PF.piecewise_poly(a, b, spec), 1e-6)):
+        xd = x.cuda().requires_grad_(True)
+        wd = wd0.detach().clone().requires_grad_(True)
+        assert PF.max_abs_fusable(xd, wd, spec)
+        y = fn(xd, wd)
+        y.backward(gy.cuda())
+        res.append((y.detach(), xd.grad, wd.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    # the saved denominators / indices against the raw forward
+    raw, _ = PF.forward_raw(x.cuda(), wd0.permute(1, 2, 0).contiguous(), spec)
+    den = torch.empty(B, device="cuda")
+    amax = torch.empty(B, device="cuda", dtype=torch.int32)
+    packed = PF.pack_weights(wd0.permute(1, 2, 0).contiguous(), spec, B)
+    y3 = torch.empty(B, O, device="cuda")
+    rc = lib.pp_forward_max_abs_ws_f32(
+        PF._ptr(x.cuda()), PF._ptr(wd0.permute(1, 2, 0).contiguous()), PF._ptr(y3), PF._ptr(den),
+        PF._ptr(amax), PF._ptr(packed), packed.numel(), B, I, O, n, S, int(disc), 2.0,
+        spec.node_array(), 1.0, 1e-6, PF._stream(den.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y3, res[0][0])
+    assert torch.equal(den, raw.abs().amax(dim=1) + 1e-6)
+    first = (raw.abs() == raw.abs().amax(dim=1, keepdim=True)).int().argmax(dim=1)
+    assert torch.equal(amax.long(), first)
+    assert rel_err(res[0][1], res[1][1]) <= 2e-5 and rel_err(res[0][2], res[1][2]) <= 2e-5
+    # the fp64 oracle of the pair, the fp32 evaluation of the same formulation as yardstick
+    rows = slice(0, 1200)
+    xo = x[rows].float().clone().requires_grad_(True)
+    wo = w.double().requires_grad_(True)
+    yo = po.max_abs_normalization_last(po.piecewise_forward_f64(xo, wo, n, S, disc), 1e-6)
+    assert rel_err(res[0][0][rows].cpu(), yo.detach()) <= 5 * TOL
+    if B <= 1200:
+        yo.backward(gy.double())
+        x32 = x.float().clone().requires_grad_(True)
+        w32 = w.float().clone().requires_grad_(True)
+        po.max_abs_normalization_last(po.piecewise_forward(x32, w32, n, S, disc), 1e-6).backward(gy.float())
+        for got, ref, ref32 in ((res[0][1].cpu(), xo.grad, x32.grad), (res[0][2].cpu(), wo.grad, w32.grad)):
+            e, e32 = rel_err(got, ref), rel_err(ref32, ref)
+            assert e <= max(5 * TOL, 2 * e32), (e, e32)
+
+
+def test_high_order_mlp_with_max_abs_on_matrix_core_layers():
+    """cfg2-like network with normalization=MaxAbsNormalizationLast: the hidden layers take the
+    fused matrix-core kernel; same outputs as one module at a time."""
+    import language_interpolation_amd as lia
+    torch.manual_seed(6)
+    net = lia.HighOrderMLP(layer_type="continuous", n=3, in_width=16, out_width=128,
+                           hidden_layers=2, hidden_width=250, in_segments=128, out_segments=2,
+                           hidden_segments=2, n_in=2, normalization=lia.MaxAbsNormalizationLast,
+                           device="cuda")
+    x = (torch.rand(1000, 16, device="cuda") * 2 - 1)
+    gy = torch.randn(1000, 128, device="cuda")
+    y1 = net(x)
+    y1.backward(gy)
+    g1 = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    y2 = net.model(x)  # nn.Sequential: one module at a time
+    y2.backward(gy)
+    g2 = [p.grad.clone() for p in net.parameters()]
+    assert torch.equal(y1, y2)
+    for a, b in zip(g1, g2):
+        assert rel_err(a.cpu(), b.cpu()) <= 5 * TOL
+
+
 # BASELINE layer shapes at the bench batch (dense-regime layers) / a quarter of it (many-segment
 # layers: the fp64 oracle's expanded basis is B*I*K doubles)
 ROWWISE_SHAPES = [
