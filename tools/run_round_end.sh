@@ -1,6 +1,7 @@
-# full GPU suite, bench, bench under rocprofv3 (kernel stats) -- round 3, after the register-accumulator work
+# Full GPU suite, bench, bench under rocprofv3 (kernel stats): what the profiles/rNN_*_bench* files come from.
+#   gpurun --timeout 1200 -- bash tools/run_round_end.sh
 R=$GRAFT_REPO_ROOT
-D=$R/gpurun_out/r3final; mkdir -p $D
+D=$R/gpurun_out/round_end; mkdir -p $D
 cd $R
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > $D/gpu_tests.txt 2>&1 || { tail -30 $D/gpu_tests.txt; exit 1; }
 tail -3 $D/gpu_tests.txt
