@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256 * G, (RM == 1 && NT == 2 && G == 2 && K == 5) ?
       }
     });
     PP_TICK(4)
-    if (amax_out) {
+    if (SC::kRanged && amax_out) {  // (fp16x2 scheme only: folds away in the bf16x3 instantiations)
       // fused MaxAbsNormalizationLast over the row (the block holds whole rows: grid.y == 1).
       // The maximum of a set does not depend on the order it is taken in and the division is
       // the correctly rounded one: bit-identical to this kernel + pp_max_abs_fwd_kernel.
