@@ -199,13 +199,18 @@ def roofline_for_hidden_layer(B, dev):
 
 def roofline_hbm(B, dev):
     """The HBM-bound layers of BASELINE (many segments: SURVEY.md 8d rows 'cfg3 hidden' and
-    'cfg4 input'), timed live per entry point at the bench batch and at the reference batch:
+    'cfg4 input', plus the cfg3 layer with the reference's n_hidden quirk), timed live per entry
+    point at the bench batch and at the reference batch:
     algorithmic bytes (every operand touched once per pass, dense gw) over the sum of the
     entry-point times, as a fraction of 8 TB/s."""
     out = []
     for name, disc, n, S, I, O, kind, first, ref_rows in (
             ("cfg3 hidden (discontinuous n=1 200->200 S=150)", True, 1, 150, 200, 200, "normal", False, 1000),
-            ("cfg4 input (discontinuous n=2 16->1000 S=128)", True, 2, 128, 16, 1000, "char", True, 256)):
+            ("cfg4 input (discontinuous n=2 16->1000 S=128)", True, 2, 128, 16, 1000, "char", True, 256),
+            # the same cfg3 layer as the reference's select_network really builds it: hidden layers get
+            # n_hidden = cfg.net.n_in = 2 (networks.py:870; SURVEY.md 8a "reference quirk"), K = 300
+            ("cfg3 hidden as select_network builds it (discontinuous n=2 200->200 S=150)", True, 2, 150,
+             200, 200, "normal", False, 1000)):
         for rows in (B, ref_rows):
             t, methods, K = time_layer(rows, disc, n, S, I, O, dev, kind, first, iters=10)
             W = I * K * O
