@@ -294,6 +294,40 @@ def test_weight_gradient_sums_to_the_column_sums_of_gy_at_full_size(case):
         assert rel_err(gw, gs) <= TOL
 
 
+# (disc, n, S, I, O): many-segment layers with a derivative (n >= 2) above 4096 rows
+BWDX_LARGE = [
+    (True, 2, 150, 200, 200),    # cfg3 hidden as select_network builds it
+    (False, 3, 37, 50, 72),      # n = 3, ragged inputs / outs
+    (True, 2, 128, 16, 1000),    # four out chunks
+    (False, 2, 64, 100, 130),    # O % 4 != 0: two floats per lane
+]
+
+
+@pytest.mark.parametrize("shape", BWDX_LARGE, ids=lambda c: "-".join(str(v) for v in c))
+def test_large_batch_gather_backward_input(shape):
+    """Above 4096 rows the gather backward-input walks one input at a time (the unrolled
+    variant is slower once many waves share a SIMD): against the fp64 oracle on a slice of the
+    rows, against the medium-batch variant of the kernel on the same rows, and the same bits on
+    a second launch.  (A variant that reduced 16 inputs' partial dot products with one butterfly
+    over the lanes passed this test and ran no faster -- 297 vs 301 us on the first shape at
+    16384 rows: the kernel waits for its 5.2 GB of table rows, not for its reductions.)"""
+    disc, n, S, I, O = shape
+    PF = _pf()
+    B = 5003
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "char" if I == 16 else "normal", seed=41)
+    xd, gyd = x.cuda(), gy.cuda()
+    w_t = w.cuda().permute(1, 2, 0).contiguous()
+    spec = PF.make_spec(n, S, disc, bwd_x_method="gather", in_features=I)
+    gx = PF.backward_input_raw(xd, gyd, w_t, spec)
+    assert torch.equal(PF.backward_input_raw(xd, gyd, w_t, spec), gx)
+    head = slice(0, 4096)
+    gx_m = PF.backward_input_raw(xd[head].contiguous(), gyd[head].contiguous(), w_t, spec)
+    assert rel_err(gx[head], gx_m) <= 2e-6
+    rows = slice(B - 900, B)
+    ref = oracle_all(x[rows], w, gy[rows], n, S, disc)
+    assert rel_err(gx[rows].cpu(), ref["gx"]) <= TOL
+
+
 # (disc, n, S, I, O, B, dist, out_scale): the small-batch weight gradient (PP_BWD_W_DIRECT)
 DIRECT_CASES = [
     (True, 2, 128, 16, 1000, 256, "char", 1.0),         # cfg4 input layer at the reference's batch
