@@ -105,6 +105,10 @@ enum {
   PP_BWD_X_DENSE = 2,
   PP_BWD_X_FP16X2 = 4, /* same on fp16 MFMA, operands split 2-way, weights scaled per tensor and gy per
                           (row, 128-out chunk) by powers of two; needs a workspace */
+  PP_BWD_X_TILE = 5,   /* many-segment layers with n >= 2 at large batches (round 3): the row-tile
+                          forward's slab stream and LDS gathers, gy of a 1024-row x 64-out tile in
+                          registers, dot-product pieces handed to the row's lane by DPP rotation;
+                          needs a workspace (records + one partial gx per out chunk); I % 4 == 0 */
   PP_BWD_X_BF16X3 = 3 /* gy x w^T on bf16 MFMA, operands split 3-way; needs a workspace:
                          pp_backward_input_ws_f32 */
 };

@@ -22,13 +22,13 @@ OPT_MAX_TENSORS = 32
 METHOD_AUTO = 0
 WS_PREPACKED = 0x100
 FWD_GATHER, FWD_DENSE, FWD_BF16X3, FWD_FP16X2, FWD_SLAB, FWD_TILE = 1, 2, 3, 4, 5, 6
-BWD_X_GATHER, BWD_X_DENSE, BWD_X_BF16X3, BWD_X_FP16X2 = 1, 2, 3, 4
+BWD_X_GATHER, BWD_X_DENSE, BWD_X_BF16X3, BWD_X_FP16X2, BWD_X_TILE = 1, 2, 3, 4, 5
 BWD_W_ATOMIC, BWD_W_SORT, BWD_W_DENSE, BWD_W_BF16X3, BWD_W_FP16X2, BWD_W_REGACC = 1, 2, 3, 4, 5, 6
 BWD_W_DIRECT = 7
 
 FWD_METHODS = {"auto": 0, "gather": 1, "dense": 2, "bf16x3": 3, "fp16x2": 4, "slab": 5,
                "tile": 6}
-BWD_X_METHODS = {"auto": 0, "gather": 1, "dense": 2, "bf16x3": 3, "fp16x2": 4}
+BWD_X_METHODS = {"auto": 0, "gather": 1, "dense": 2, "bf16x3": 3, "fp16x2": 4, "tile": 5}
 BWD_W_METHODS = {"auto": 0, "atomic": 1, "sort": 2, "dense": 3, "bf16x3": 4, "fp16x2": 5,
                  "regacc": 6, "direct": 7}
 

@@ -125,6 +125,8 @@ const char* pp_error_string(int code) {
   }
 }
 
+static int bwd_x_auto(const PPShape& sh, bool have_ws);
+
 int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuous, float length) {
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f);
@@ -134,9 +136,7 @@ int pp_auto_method(int pass, int B, int I, int O, int n, int S, int discontinuou
     case 0: return matrix_core_fwd(sh) ? (pp_bf3_supported(sh) ? PP_FWD_FP16X2 : PP_FWD_DENSE)
                    : tile_fwd(sh, true) ? PP_FWD_TILE
                                         : (pp_slab_fwd_preferred(sh) ? PP_FWD_SLAB : PP_FWD_GATHER);
-    case 1: return matrix_core_bwd_x(sh)
-                       ? (pp_bf3_bwd_x_supported(sh) && B >= 256 ? PP_BWD_X_FP16X2 : PP_BWD_X_DENSE)
-                       : PP_BWD_X_GATHER;
+    case 1: return bwd_x_auto(sh, true);
     case 2:
       // (fp16x2 from 4096 rows for layers wider than 128 outs: 38.5 vs 42 us f32-MFMA on 250 -> 250;
       // the 128-out layers stay on the f32-MFMA kernel up to 8192: 27 vs 30 us at 4096)
@@ -316,7 +316,8 @@ int pp_forward_noalloc_f32(const float* x, const float* w_t, float* y, int32_t* 
 }
 
 static int bwd_x_auto(const PPShape& sh, bool have_ws) {
-  if (!matrix_core_bwd_x(sh)) return PP_BWD_X_GATHER;
+  if (!matrix_core_bwd_x(sh))
+    return have_ws && pp_tile_bwd_x_preferred(sh) ? PP_BWD_X_TILE : PP_BWD_X_GATHER;
   if (have_ws && pp_bf3_bwd_x_supported(sh) && sh.B >= 256) return PP_BWD_X_FP16X2;
   return PP_BWD_X_DENSE;
 }
@@ -328,6 +329,7 @@ size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int 
   if (method == PP_METHOD_AUTO) method = bwd_x_auto(sh, true);
   if ((method == PP_BWD_X_BF16X3 || method == PP_BWD_X_FP16X2) && pp_bf3_bwd_x_supported(sh))
     return pp_bf3_bwd_x_workspace_bytes(sh);
+  if (method == PP_BWD_X_TILE && pp_tile_bwd_x_supported(sh)) return pp_tile_bwd_x_workspace_bytes(sh);
   return 0;
 }
 
@@ -354,6 +356,8 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     method = bwd_x_auto(sh, workspace != nullptr);
     if (method == PP_BWD_X_FP16X2 && workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh))
       method = PP_BWD_X_DENSE;
+    if (method == PP_BWD_X_TILE && workspace_bytes < pp_tile_bwd_x_workspace_bytes(sh))
+      method = PP_BWD_X_GATHER;
   }
   hipStream_t st = (hipStream_t)stream;
   if (method == PP_BWD_X_GATHER)
@@ -361,6 +365,11 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
   if (method == PP_BWD_X_DENSE) {
     if (!pp_dense_supported(sh)) return PP_ERR_METHOD;
     return hip_rc(pp_launch_bwd_input_dense(x, gy, w_t, gx, sh, tab, st));
+  }
+  if (method == PP_BWD_X_TILE) {
+    if (!pp_tile_bwd_x_supported(sh)) return PP_ERR_METHOD;
+    if (!workspace || workspace_bytes < pp_tile_bwd_x_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
+    return hip_rc(pp_launch_bwd_x_tile(x, gy, w_t, gx, workspace, sh, tab, st));
   }
   if (method == PP_BWD_X_BF16X3 || method == PP_BWD_X_FP16X2) {
     if (!pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;

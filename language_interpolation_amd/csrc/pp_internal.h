@@ -45,6 +45,12 @@ hipError_t pp_launch_fwd_slab(const float* x, const float* wt, float* y, int32_t
 bool pp_tile_fwd_supported(const PPShape& sh);
 bool pp_tile_fwd_preferred(const PPShape& sh);
 size_t pp_tile_fwd_workspace_bytes(const PPShape& sh, bool with_norm);
+// backward-input on the same tiles (n >= 2, I % 4 == 0)
+bool pp_tile_bwd_x_supported(const PPShape& sh);
+bool pp_tile_bwd_x_preferred(const PPShape& sh);
+size_t pp_tile_bwd_x_workspace_bytes(const PPShape& sh);
+hipError_t pp_launch_bwd_x_tile(const float* x, const float* gy, const float* wt, float* gx, void* ws,
+                                const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_fwd_tile(const float* x, const float* wt, float* y, int32_t* seg, void* ws,
                               float* rstd, float ln_eps, const PPShape& sh, const BasisTab& tab,
                               hipStream_t st);

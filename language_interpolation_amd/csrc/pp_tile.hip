@@ -141,7 +141,8 @@ struct TilePlan {
 // a unit with one coalesced load: rec[i][plane][Bpad], plane 0 = byte offset of the row's first
 // active slab row (s * stride * 256), planes 1..N = the basis values (N > 1 only).  x is read
 // in 64 x 64 tiles and transposed through LDS.  Rows past the batch get offset 0 / basis 0.
-template <int N>
+// DERIV (backward-input): planes 1..N hold dl_m/dx * out_scale instead of the basis values.
+template <int N, bool DERIV = false>
 __global__ __launch_bounds__(256) void pp_tile_prep_kernel(const float* __restrict__ x,
                                                           int32_t* __restrict__ rec,
                                                           int32_t* __restrict__ seg_out, PPShape sh,
@@ -174,7 +175,16 @@ __global__ __launch_bounds__(256) void pp_tile_prep_kernel(const float* __restri
     const bool live = row < sh.B;
     int32_t* r = rec + (size_t)i * P * Bpad + row;
     r[0] = live ? s * sh.stride * (CH * 4) : 0;
-    if constexpr (N > 1) {
+    if constexpr (N > 1 && DERIV) {
+      float dxi_dx;
+      const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, &dxi_dx);
+      float l[N], dl[N];
+      pp_lagrange_d<N>(xi, tab, l, dl);
+      const float chain = dxi_dx * sh.out_scale;  // (the gather kernel's order: dl * chain)
+#pragma unroll
+      for (int m = 0; m < N; ++m)
+        r[(size_t)(1 + m) * Bpad] = live ? __float_as_int(dl[m] * chain) : 0;
+    } else if constexpr (N > 1) {
       const float xi = pp_local_coord(xv, s, sh.length, sh.half, sh.Sf, nullptr);
       float l[N];
       pp_lagrange<N>(xi, tab, l);
@@ -341,6 +351,141 @@ __global__ __launch_bounds__(64 * NW) void pp_fwd_tile_kernel(
   }
 }
 
+// Backward-input on the same tiles (round 3): gx[b,i] = sum_m dl_m(b,i) * <gy[b,:], w_t[i, k0+m, :]>.
+// The workgroup keeps the gy values of its rows x 64 outs in registers -- in the gathers' skewed
+// layout: g[J] of lane (slot, q) is gy[row of the lane rot_i<J> names][4q..4q+3] -- streams the
+// slabs exactly as the forward does, and at step J every lane has a 4-float piece of the dot
+// product of ANOTHER lane's row; the piece goes to the row's owner through the opposite rotation
+// (DPP row_ror:16-J on the add).  16 steps later the owner has its row's dot product over the 64
+// outs, multiplies by its record's derivative values and stores part[chunk][row][i]; the out
+// chunks are summed by pp_tile_reduce_kernel.  Inputs are independent: an input split only adds
+// workgroups, no partial sums.  n >= 2 (n = 1 has no derivative), I % 4 == 0 (the chunk sum).
+template <int N, int NW, int UW>
+__global__ __launch_bounds__(64 * NW) void pp_bwdx_tile_kernel(
+    const int32_t* __restrict__ rec, const float* __restrict__ wt, const float* __restrict__ gy,
+    float* __restrict__ out, PPShape sh, int KP, int Bpad, int nchunk, int per_split,
+    long part_stride, int nbuf) {
+  constexpr int P = N + 1;
+  extern __shared__ __attribute__((aligned(16))) float slab[];  // [nbuf][KP][CH]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int chunk = blockIdx.x % nchunk, split = blockIdx.x / nchunk;
+  const int o0 = chunk * CH;
+  const int row0 = (blockIdx.y * NW + wave) * (UW * 64);
+  const int i_lo = split * per_split, i_hi = min(sh.I, i_lo + per_split);
+  const int bufB = KP * CH * 4;
+  const int q16 = (lane & 15) * 16;
+  const int nq = KP / 4;
+  const unsigned slab_base = (unsigned)(__UINTPTR_TYPE__)(lds_void*)slab;
+  const int ocol = min(o0 + (lane & 15) * 4, sh.O - 4);
+  const int cnt = (nq + NW - 1) / NW;
+  auto slab_load = [&](int i, int buf) {
+    const float* src = wt + (size_t)i * sh.K * sh.O + ocol;
+    for (int t = 0; t < cnt; ++t) {
+      const int q = min(wave + t * NW, nq - 1);
+      const int row = min(q * 4 + (lane >> 4), sh.K - 1);
+      glds16(src + (size_t)row * sh.O, slab_base + (unsigned)(buf * bufB + q * (4 * CH * 4)));
+    }
+  };
+
+  // gy of the rows this lane works for, step by step (columns past O: 0)
+  float g[UW][16][4];
+  const int oc = o0 + (lane & 15) * 4;
+#pragma unroll
+  for (int u = 0; u < UW; ++u)
+    static_for<16>([&](auto Jc) {
+      constexpr int J = decltype(Jc)::value;
+      const int row = row0 + u * 64 + rot_i<J>(lane);
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (row < sh.B && oc < sh.O) v = *reinterpret_cast<const float4*>(gy + (size_t)row * sh.O + oc);
+      g[u][J][0] = v.x; g[u][J][1] = v.y; g[u][J][2] = v.z; g[u][J][3] = v.w;
+    });
+
+  const int32_t* rbase = rec + row0 + lane;
+  auto load_rec = [&](int i, int (&dst)[UW][P]) {
+#pragma unroll
+    for (int u = 0; u < UW; ++u)
+      if (row0 + u * 64 < sh.B) {  // wave-uniform
+#pragma unroll
+        for (int pl = 0; pl < P; ++pl) dst[u][pl] = rbase[((size_t)i * P + pl) * Bpad + u * 64];
+      }
+  };
+
+  const char* slab_bytes = reinterpret_cast<const char*>(slab);
+  float* dst = out + (size_t)chunk * part_stride;
+  int rn[UW][P];
+  load_rec(i_lo, rn);
+  for (int a = 0; a < nbuf - 1; ++a)
+    if (i_lo + a < i_hi) slab_load(i_lo + a, a);
+  dma_wait((nbuf - 2) * cnt);
+  __syncthreads();
+  int buf = 0, bnew = nbuf - 1;
+  float pend[UW][4];
+  for (int i = i_lo; i < i_hi; ++i) {
+    int rc[UW][P];
+#pragma unroll
+    for (int u = 0; u < UW; ++u)
+#pragma unroll
+      for (int pl = 0; pl < P; ++pl) rc[u][pl] = rn[u][pl];
+    if (i + 1 < i_hi) load_rec(i + 1, rn);
+    if (i + nbuf - 1 < i_hi) slab_load(i + nbuf - 1, bnew);
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      if (row0 + u * 64 < sh.B) {  // wave-uniform: every lane takes part in the rotations
+        const int koff = rc[u][0] + buf * bufB;
+        // BS steps' reads in flight together (two for n >= 3: four spilled at 128 registers);
+        // BS partial sums a node, so that the 16 rotated adds are not one dependent chain
+        constexpr int BS = N >= 3 ? 2 : 4;
+        float res[N][BS];
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+          for (int t = 0; t < BS; ++t) res[m][t] = 0.0f;
+        static_for<16 / BS>([&](auto G) {
+          float4 w[BS][N];
+          static_for<BS>([&](auto T) {
+            constexpr int J = decltype(G)::value * BS + decltype(T)::value;
+            const int a = rot_i<J>(koff) + q16;
+#pragma unroll
+            for (int m = 0; m < N; ++m)
+              w[decltype(T)::value][m] =
+                  *reinterpret_cast<const float4*>(slab_bytes + a + m * (CH * 4));
+          });
+          static_for<BS>([&](auto T) {
+            constexpr int TT = decltype(T)::value;
+            constexpr int J = decltype(G)::value * BS + TT;
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+              float d = w[TT][m].x * g[u][J][0];
+              d = fmaf(w[TT][m].y, g[u][J][1], d);
+              d = fmaf(w[TT][m].z, g[u][J][2], d);
+              d = fmaf(w[TT][m].w, g[u][J][3], d);
+              res[m][TT] += rot_f<(16 - J) & 15>(d);  // to the lane that owns the row
+            }
+          });
+        });
+        float v = 0.0f;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          float r = res[m][0] + res[m][1];
+          if constexpr (BS == 4) r += res[m][2] + res[m][3];
+          v = fmaf(__int_as_float(rc[u][1 + m]), r, v);
+        }
+        // four inputs' values a store (i_lo and I are multiples of 4)
+        pend[u][(i - i_lo) & 3] = v;
+        const int row = row0 + u * 64 + lane;
+        if (((i - i_lo) & 3) == 3 && row < sh.B)
+          *reinterpret_cast<float4*>(dst + (size_t)row * sh.I + (i - 3)) =
+              make_float4(pend[u][0], pend[u][1], pend[u][2], pend[u][3]);
+      }
+    }
+    dma_wait(i + nbuf - 1 < i_hi ? (nbuf - 2) * cnt : 0);
+    __syncthreads();
+    buf = buf + 1 == nbuf ? 0 : buf + 1;
+    bnew = bnew + 1 == nbuf ? 0 : bnew + 1;
+  }
+}
+
 // y = sum of the nsplit partial outputs in split order (float4 per thread).
 __global__ __launch_bounds__(256) void pp_tile_reduce_kernel(const float* __restrict__ part,
                                                             float* __restrict__ y, long total4,
@@ -487,7 +632,78 @@ hipError_t tile_dispatch(const float* x, const float* wt, float* out, int32_t* s
   return hipErrorInvalidValue;
 }
 
+template <int N, int NW, int UW>
+hipError_t launch_bwdx_tile(const int32_t* rec, const float* wt, const float* gy, float* out,
+                            const PPShape& sh, const TilePlan& p, long part_stride, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute((const void*)pp_bwdx_tile_kernel<N, NW, UW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((pp_bwdx_tile_kernel<N, NW, UW>), dim3(p.nchunk * p.nsplit, p.ntile),
+                     dim3(64 * NW), p.lds, st, rec, wt, gy, out, sh, p.KP, p.Bpad, p.nchunk,
+                     p.per_split, part_stride, p.nbuf);
+  return hipGetLastError();
+}
+
+template <int N>
+hipError_t bwdx_tile_dispatch(const float* x, const float* wt, const float* gy, float* out,
+                              int32_t* rec, const PPShape& sh, const BasisTab& tab,
+                              const TilePlan& p, long part_stride, hipStream_t st) {
+  hipLaunchKernelGGL((pp_tile_prep_kernel<N, true>), dim3((sh.B + 63) / 64, (sh.I + 63) / 64),
+                     dim3(256), 0, st, x, rec, nullptr, sh, tab, p.Bpad);
+#define PP_TILE_CASE(NW_, UW_) \
+  if (p.NW == NW_ && p.UW == UW_)  \
+    return launch_bwdx_tile<N, NW_, UW_>(rec, wt, gy, out, sh, p, part_stride, st);
+  PP_TILE_CASE(16, 1) PP_TILE_CASE(4, 2) PP_TILE_CASE(4, 1)
+#undef PP_TILE_CASE
+  return hipErrorInvalidValue;
+}
+
 }  // namespace
+
+bool pp_tile_bwd_x_supported(const PPShape& sh) {
+  return sh.n >= 2 && sh.I % 4 == 0 && tile_plan(sh).ok;
+}
+
+// Where PP_METHOD_AUTO takes it (given a workspace).  Against the gather kernel on the 200 -> 200,
+// n = 2, K = 300 layer (HIP events, us): 1000 rows 38.6 vs 31.7, 2048: 53 vs 46, 4096: 71 vs 90,
+// 8192: 105 vs 135, 16384: 168 vs 295 -- ahead once the gather kernel's table-row traffic
+// B*I*n*O*4 passes ~1.2 GB; few-input layers are first layers and have no backward-input.
+bool pp_tile_bwd_x_preferred(const PPShape& sh) {
+  if (!pp_tile_bwd_x_supported(sh) || sh.K < 64 || sh.O < 64) return false;
+  const double gather_bytes = 4.0 * sh.B * sh.I * sh.n * sh.O;
+  return sh.I >= 64 && gather_bytes >= 1.2e9;
+}
+
+// records | one partial gx per out chunk (when there is more than one)
+size_t pp_tile_bwd_x_workspace_bytes(const PPShape& sh) {
+  const TilePlan p = tile_plan(sh);
+  if (!p.ok) return 0;
+  return p.rec_bytes + (p.nchunk > 1 ? (size_t)p.nchunk * sh.B * sh.I * sizeof(float) : 0);
+}
+
+hipError_t pp_launch_bwd_x_tile(const float* x, const float* gy, const float* wt, float* gx, void* ws,
+                                const PPShape& sh, const BasisTab& tab, hipStream_t st) {
+  TilePlan p = tile_plan(sh);
+  if (!p.ok || sh.n < 2 || sh.I % 4 != 0) return hipErrorInvalidValue;
+  p.per_split = (p.per_split + 3) & ~3;  // the kernel stores four inputs' values at a time
+  p.nsplit = (sh.I + p.per_split - 1) / p.per_split;
+  int32_t* rec = static_cast<int32_t*>(ws);
+  const bool direct = p.nchunk == 1;
+  float* out = direct ? gx : reinterpret_cast<float*>(static_cast<char*>(ws) + p.rec_bytes);
+  const long part_stride = (long)sh.B * sh.I;
+  hipError_t e;
+  switch (sh.n) {
+    case 2: e = bwdx_tile_dispatch<2>(x, wt, gy, out, rec, sh, tab, p, part_stride, st); break;
+    case 3: e = bwdx_tile_dispatch<3>(x, wt, gy, out, rec, sh, tab, p, part_stride, st); break;
+    case 4: e = bwdx_tile_dispatch<4>(x, wt, gy, out, rec, sh, tab, p, part_stride, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess || direct) return e;
+  const long total4 = part_stride / 4;
+  hipLaunchKernelGGL(pp_tile_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st,
+                     out, gx, total4, total4, p.nchunk);
+  return hipGetLastError();
+}
 
 bool pp_tile_fwd_supported(const PPShape& sh) { return tile_plan(sh).ok; }
 

@@ -89,6 +89,11 @@ def test_auto_method_selection():
     # networks.py:386-425) keeps the layer off the matrix-core kernels
     assert lib.pp_auto_method(0, 256, 250, 250, 3, 2, 0, 3.0) == _lib.FWD_GATHER
     assert lib.pp_auto_method(1, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_X_GATHER
+    # many segments with a derivative (n >= 2), large batch: the row-tile backward-input
+    assert lib.pp_auto_method(1, 16384, 200, 200, 2, 150, 1, 2.0) == _lib.BWD_X_TILE
+    assert lib.pp_auto_method(1, 2048, 200, 200, 2, 150, 1, 2.0) == _lib.BWD_X_GATHER
+    assert lib.pp_backward_input_workspace_bytes(16384, 200, 200, 2, 150, 1, 2.0, _lib.BWD_X_TILE) > \
+        4 * 16384 * 200 * 4
     assert lib.pp_auto_method(2, 256, 250, 250, 3, 2, 0, 3.0) == _lib.BWD_W_REGACC
     assert lib.pp_packed_weights_bytes(250, 250, 3, 2, 0, 3.0) == 0
     assert lib.pp_forward_layer_norm_supported(256, 250, 250, 3, 2, 0, 3.0) == 2  # gather-fused

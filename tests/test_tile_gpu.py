@@ -178,3 +178,65 @@ def test_tile_forward_at_the_bench_batch(shape):
     ones = torch.ones_like(w_t)
     y1, _ = PF.forward_raw(xd * 1.7, ones, tile)
     assert float((y1 - I).abs().max()) <= 1e-5 * I
+
+
+# (disc, n, S, I, O, B, dist): the row-tile backward-input (PP_BWD_X_TILE)
+TILE_BWDX_CASES = [
+    (True, 2, 150, 200, 200, 1100, "normal"),    # cfg3 hidden as select_network builds it: K = 300
+    (True, 2, 128, 16, 1000, 1030, "char"),      # 16 out chunks summed, no input split
+    (False, 2, 128, 16, 200, 700, "char"),       # continuous, 8-out tail chunk
+    (False, 3, 20, 36, 72, 200, "edges"),        # n = 3, boundary values
+    (False, 4, 30, 64, 128, 513, "uniform"),     # n = 4, one row past a 512-row tile
+    (True, 3, 50, 132, 260, 257, "normal"),      # ragged input split, 4-out tail chunk
+]
+
+
+@pytest.mark.parametrize("case", TILE_BWDX_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_tile_backward_input_matches_oracle(case):
+    disc, n, S, I, O, B, dist = case
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, dist, seed=27)
+    ref = oracle_all(x, w, gy, n, S, disc)
+    xd, gyd = x.cuda(), gy.cuda()
+    w_t = w.cuda().permute(1, 2, 0).contiguous()
+    tile = PF.make_spec(n, S, disc, bwd_x_method="tile", in_features=I)
+    gx = PF.backward_input_raw(xd, gyd, w_t, tile)
+    assert torch.equal(PF.backward_input_raw(xd, gyd, w_t, tile), gx)  # fixed order of every sum
+    assert rel_err(gx.cpu(), ref["gx"]) <= TOL, rel_err(gx.cpu(), ref["gx"])
+    gather = PF.make_spec(n, S, disc, bwd_x_method="gather", in_features=I)
+    assert rel_err(gx, PF.backward_input_raw(xd, gyd, w_t, gather)) <= 2e-6
+
+
+def test_tile_backward_input_with_scale_length_and_refusals():
+    PF, L = _pf(), _lib()
+    disc, n, S, I, O, B = False, 3, 37, 44, 96, 600
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "edges", seed=28)
+    x = x * 1.5
+    ref = oracle_all(x, w, gy, n, S, disc, length=3.0, rescale_output=True)
+    spec = PF.make_spec(n, S, disc, bwd_x_method="tile", in_features=I, length=3.0, rescale_output=True)
+    gx = PF.backward_input_raw(x.cuda(), gy.cuda(), w.cuda().permute(1, 2, 0).contiguous(), spec)
+    assert rel_err(gx.cpu(), ref["gx"]) <= TOL
+    for (disc, n, S, I, O) in ((True, 1, 150, 16, 64), (True, 2, 40, 18, 64), (True, 2, 40, 16, 66)):
+        x, w, gy = make_inputs(64, I, O, n, S, disc, "normal", seed=1)
+        spec = PF.make_spec(n, S, disc, bwd_x_method="tile", in_features=I)
+        with pytest.raises(L.PPHipError, match="inapplicable"):
+            PF.backward_input_raw(x.cuda(), gy.cuda(), w.cuda().permute(1, 2, 0).contiguous(), spec)
+
+
+@pytest.mark.parametrize("shape", [(True, 2, 150, 200, 200), (False, 2, 128, 64, 256)],
+                         ids=lambda c: "-".join(str(v) for v in c))
+def test_tile_backward_input_at_the_bench_batch(shape):
+    """16384 rows: against the gather kernel (oracle-checked, different summation order), same
+    bits on a second launch, and linearity in gy (gx(a*gy) = a*gx(gy) for a power of two, exactly)."""
+    disc, n, S, I, O = shape
+    B = 16384
+    PF = _pf()
+    x, w, gy = make_inputs(B, I, O, n, S, disc, "normal", seed=29)
+    xd, gyd = x.cuda(), gy.cuda()
+    w_t = w.cuda().permute(1, 2, 0).contiguous()
+    tile = PF.make_spec(n, S, disc, bwd_x_method="tile", in_features=I)
+    gather = PF.make_spec(n, S, disc, bwd_x_method="gather", in_features=I)
+    gx = PF.backward_input_raw(xd, gyd, w_t, tile)
+    assert torch.equal(PF.backward_input_raw(xd, gyd, w_t, tile), gx)
+    assert rel_err(gx, PF.backward_input_raw(xd, gyd, w_t, gather)) <= 2e-6
+    assert torch.equal(PF.backward_input_raw(xd, gyd * 4.0, w_t, tile), gx * 4.0)

@@ -88,7 +88,7 @@ def main():
                                 args.iters)
                 rows.append((f"fwd+LN/{mode}", t, 4 * (B * I + B * O + W), 2 * B * I * O * n))
             if not first and not args.fwd_only:
-                for m in ("gather", "dense", "bf16x3", "fp16x2"):
+                for m in ("gather", "dense", "bf16x3", "fp16x2", "tile"):
                     spec = PF.make_spec(n, S, disc, bwd_x_method=m)
                     try:
                         t = time_fn(lambda: PF.backward_input_raw(x, gy, w_t, spec), args.iters)
