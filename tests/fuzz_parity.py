@@ -51,7 +51,7 @@ def draw_case(rng: random.Random, large: bool = False):
 
 
 FWD = ["gather", "dense", "bf16x3", "fp16x2", "slab", "tile"]
-BWD_X = ["gather", "dense", "bf16x3", "fp16x2"]
+BWD_X = ["gather", "dense", "bf16x3", "fp16x2", "tile"]
 BWD_W = ["atomic", "sort", "dense", "bf16x3", "fp16x2", "regacc", "direct"]
 
 
