@@ -106,7 +106,7 @@ bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >
 
 extern "C" {
 
-int pp_version(void) { return 200; }
+int pp_version(void) { return 300; }  // round 3: PP_FWD_TILE, PP_BWD_X_TILE, pp_forward_max_abs_ws_f32, regacc in parts
 
 const char* pp_error_string(int code) {
   switch (code) {
