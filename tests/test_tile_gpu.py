@@ -2,7 +2,9 @@
 segment ids bit-exact, outputs within 1e-5 of the fp64 evaluation; every template variant
 (rows per workgroup, nodes per segment, aligned / unaligned input rows), ragged tails in rows,
 outs and inputs, the input split with its fixed-order sum, the LayerNorm fused into that sum,
-and the full BASELINE shapes through size-independent properties."""
+and the full BASELINE shapes through size-independent properties.  Second half: the row-tile
+backward-input (PP_BWD_X_TILE) against the oracle, the gather kernel, and exact linearity in gy
+at the bench batch."""
 import pytest
 import torch
 
