@@ -258,6 +258,49 @@ int pp_layer_norm_fwd_f32(const float* x, float* y, float* rstd, int B, int D, f
 int pp_layer_norm_bwd_f32(const float* y, const float* gy, const float* rstd, float* gx, int B,
                           int D, void* stream);
 
+/* LayerNorm backward folded into the backward of the layer BELOW the normalisation (round 3;
+ * the layer -> LazyLayerNormLastDim -> layer chains of HighOrderMLP, networks.py:866-882 with
+ * normalization=LazyLayerNormLastDim; replaces autograd's backward through torch.nn.LayerNorm,
+ * networks.py:72-91).  Two halves, both on the fp16x2 matrix-core kernels:
+ *
+ *  pp_backward_input_stats_ws_f32 -- pp_backward_input_ws_f32 of the layer ABOVE the
+ *    normalisation (its x is the normalisation's output), which also leaves the two row sums the
+ *    LayerNorm backward needs: row_stats[t][b] = (sum_i gx[b,i], sum_i gx[b,i] * x[b,i]) over
+ *    the inputs of tile t (32 inputs a tile, pp_row_stats_tiles(I) tiles, float2 per row:
+ *    8 * tiles * B bytes).  method: PP_METHOD_AUTO or PP_BWD_X_FP16X2 (also | PP_WS_PREPACKED);
+ *    PP_ERR_METHOD when that resolves to a kernel without the epilogue
+ *    (pp_backward_input_stats_supported says which shapes have it under PP_METHOD_AUTO).
+ *
+ *  pp_backward_weight_layer_norm_f32 -- pp_backward_weight_f32 of the layer BELOW, given the
+ *    gradient at the normalisation's OUTPUT (gy = the gx above), the normalisation's output
+ *    y_norm, its rstd and those row sums (stats_tiles = pp_row_stats_tiles(O) of this layer):
+ *    the pass that splits the gradient for the matrix cores computes
+ *    g = rstd * (gy - mean(gy) - y_norm * mean(gy * y_norm)) on the way (the expression of
+ *    pp_layer_norm_bwd_f32, the means from the row sums), writes it to g_out[B,O] for the layer's
+ *    own backward-input call, and the weight gradient is taken from it.  method: PP_METHOD_AUTO
+ *    or PP_BWD_W_FP16X2; PP_ERR_METHOD where PP_METHOD_AUTO would not run the fp16x2 kernel
+ *    (pp_backward_weight_layer_norm_supported).  Workspace: pp_workspace_bytes(PP_BWD_W_FP16X2).
+ *    Same gw_t as pp_layer_norm_bwd_f32 + pp_backward_weight_f32 up to the summation order of
+ *    the two means.
+ * Measured on MI355X (250 -> 250, 16384 rows): the folded pass 20.5 us against 9.3 + 8.4 us for the
+ * two kernels it replaces, +1.6 us for the row sums above -- slower, so the Python host keeps it
+ * switched off (functional.FOLD_LAYER_NORM_BACKWARD); profiles/r03_k_ln_fold.txt. */
+int pp_row_stats_tiles(int I);
+int pp_backward_input_stats_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                      float length);
+int pp_backward_input_stats_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
+                                   float* row_stats, void* workspace, size_t workspace_bytes, int B,
+                                   int I, int O, int n, int S, int discontinuous, float length,
+                                   const float* nodes, float out_scale, int method, void* stream);
+int pp_backward_weight_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                            float length);
+int pp_backward_weight_layer_norm_f32(const float* x, const float* gy, const float* y_norm,
+                                      const float* rstd, const float* row_stats, int stats_tiles,
+                                      float* g_out, float* gw_t, void* workspace,
+                                      size_t workspace_bytes, int B, int I, int O, int n, int S,
+                                      int discontinuous, float length, const float* nodes,
+                                      float out_scale, int method, void* stream);
+
 /* MaxAbsNormalizationLast of high-order-layers-torch (selected at networks.py:58-59):
  * y = x / (max|x| over the last dim + eps); backward needs x and gy. D <= 1024. */
 int pp_max_abs_norm_fwd_f32(const float* x, float* y, int B, int D, float eps, void* stream);

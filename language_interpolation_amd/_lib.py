@@ -76,6 +76,19 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
          c_float, c_int, _P],
     ),
+    "pp_row_stats_tiles": (c_int, [c_int]),
+    "pp_backward_input_stats_supported": (c_int, [c_int] * 6 + [c_float]),
+    "pp_backward_input_stats_ws_f32": (
+        c_int,
+        [_P, _P, _P, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P,
+         c_float, c_int, _P],
+    ),
+    "pp_backward_weight_layer_norm_supported": (c_int, [c_int] * 6 + [c_float]),
+    "pp_backward_weight_layer_norm_f32": (
+        c_int,
+        [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
+         c_float, _P, c_float, c_int, _P],
+    ),
     "pp_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_weight_f32": (
         c_int,

@@ -106,7 +106,7 @@ bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >
 
 extern "C" {
 
-int pp_version(void) { return 300; }  // round 3: PP_FWD_TILE, PP_BWD_X_TILE, pp_forward_max_abs_ws_f32, regacc in parts
+int pp_version(void) { return 301; }  // round 3: PP_FWD_TILE, PP_BWD_X_TILE, pp_forward_max_abs_ws_f32, regacc in parts, LayerNorm fold
 
 const char* pp_error_string(int code) {
   switch (code) {
@@ -333,10 +333,43 @@ size_t pp_backward_input_workspace_bytes(int B, int I, int O, int n, int S, int 
   return 0;
 }
 
+static int backward_input_impl(const float* x, const float* gy, const float* w_t, float* gx,
+                               float* row_stats, void* workspace, size_t workspace_bytes, int B,
+                               int I, int O, int n, int S, int discontinuous, float length,
+                               const float* nodes, float out_scale, int method, void* stream);
+
 int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
                              void* workspace, size_t workspace_bytes, int B, int I, int O, int n,
                              int S, int discontinuous, float length, const float* nodes,
                              float out_scale, int method, void* stream) {
+  return backward_input_impl(x, gy, w_t, gx, nullptr, workspace, workspace_bytes, B, I, O, n, S,
+                             discontinuous, length, nodes, out_scale, method, stream);
+}
+
+int pp_row_stats_tiles(int I) { return I > 0 ? (I + 31) / 32 : 0; }
+
+int pp_backward_input_stats_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                      float length) {
+  PPShape sh;
+  if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
+  return bwd_x_auto(sh, true) == PP_BWD_X_FP16X2 ? 1 : 0;
+}
+
+int pp_backward_input_stats_ws_f32(const float* x, const float* gy, const float* w_t, float* gx,
+                                   float* row_stats, void* workspace, size_t workspace_bytes, int B,
+                                   int I, int O, int n, int S, int discontinuous, float length,
+                                   const float* nodes, float out_scale, int method, void* stream) {
+  if (!row_stats) return PP_ERR_NULL;
+  if (!aligned16(row_stats)) return PP_ERR_ALIGN;
+  return backward_input_impl(x, gy, w_t, gx, row_stats, workspace, workspace_bytes, B, I, O, n, S,
+                             discontinuous, length, nodes, out_scale, method, stream);
+}
+
+// row_stats != nullptr: only the kernels with the row-sum epilogue (fp16x2) may run
+static int backward_input_impl(const float* x, const float* gy, const float* w_t, float* gx,
+                               float* row_stats, void* workspace, size_t workspace_bytes, int B,
+                               int I, int O, int n, int S, int discontinuous, float length,
+                               const float* nodes, float out_scale, int method, void* stream) {
   if (!x || !gy || !w_t || !gx) return PP_ERR_NULL;
   if (!aligned16(x) || !aligned16(gy) || !aligned16(w_t) || !aligned16(gx) ||
       !aligned16(workspace))
@@ -350,7 +383,7 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     if (!pp_bf3_bwd_x_supported(sh) || !pp_bf3_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < packed_weights_bytes(sh)) return PP_ERR_WORKSPACE;
     return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, true,
-                                     pp_h2_fwd_packed_bytes(sh), (hipStream_t)stream));
+                                     pp_h2_fwd_packed_bytes(sh), row_stats, (hipStream_t)stream));
   }
   if (method == PP_METHOD_AUTO) {
     method = bwd_x_auto(sh, workspace != nullptr);
@@ -359,6 +392,7 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     if (method == PP_BWD_X_TILE && workspace_bytes < pp_tile_bwd_x_workspace_bytes(sh))
       method = PP_BWD_X_GATHER;
   }
+  if (row_stats && method != PP_BWD_X_FP16X2) return PP_ERR_METHOD;
   hipStream_t st = (hipStream_t)stream;
   if (method == PP_BWD_X_GATHER)
     return hip_rc(pp_launch_bwd_input_gather(x, gy, w_t, gx, sh, tab, st));
@@ -375,7 +409,7 @@ int pp_backward_input_ws_f32(const float* x, const float* gy, const float* w_t, 
     if (!pp_bf3_bwd_x_supported(sh)) return PP_ERR_METHOD;
     if (!workspace || workspace_bytes < pp_bf3_bwd_x_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
     if (method == PP_BWD_X_FP16X2)
-      return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, false, 256, st));
+      return hip_rc(pp_launch_bwd_x_h2(x, gy, w_t, gx, workspace, sh, tab, false, 256, row_stats, st));
     return hip_rc(pp_launch_bwd_x_bf3(x, gy, w_t, gx, workspace, sh, tab, st));
   }
   return PP_ERR_METHOD;
@@ -453,6 +487,34 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
     default:
       return PP_ERR_METHOD;
   }
+}
+
+int pp_backward_weight_layer_norm_supported(int B, int I, int O, int n, int S, int discontinuous,
+                                            float length) {
+  return pp_auto_method(2, B, I, O, n, S, discontinuous, length) == PP_BWD_W_FP16X2 ? 1 : 0;
+}
+
+int pp_backward_weight_layer_norm_f32(const float* x, const float* gy, const float* y_norm,
+                                      const float* rstd, const float* row_stats, int stats_tiles,
+                                      float* g_out, float* gw_t, void* workspace,
+                                      size_t workspace_bytes, int B, int I, int O, int n, int S,
+                                      int discontinuous, float length, const float* nodes,
+                                      float out_scale, int method, void* stream) {
+  if (!x || !gy || !y_norm || !rstd || !row_stats || !g_out || !gw_t) return PP_ERR_NULL;
+  if (!aligned16(x) || !aligned16(gy) || !aligned16(y_norm) || !aligned16(row_stats) ||
+      !aligned16(g_out) || !aligned16(gw_t) || !aligned16(workspace))
+    return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (stats_tiles != pp_row_stats_tiles(O)) return PP_ERR_SHAPE;
+  if (method == PP_METHOD_AUTO) method = pp_auto_method(2, B, I, O, n, S, discontinuous, length);
+  if (method != PP_BWD_W_FP16X2 || !pp_bf3_bwd_w_supported(sh)) return PP_ERR_METHOD;
+  if (!workspace || workspace_bytes < pp_bf3_bwd_w_workspace_bytes(sh)) return PP_ERR_WORKSPACE;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_bwd_w_h2_ln(x, gy, y_norm, rstd, row_stats, stats_tiles, g_out, gw_t,
+                                      workspace, sh, tab, (hipStream_t)stream));
 }
 
 int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream) {

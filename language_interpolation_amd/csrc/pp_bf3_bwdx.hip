@@ -17,6 +17,12 @@ namespace {
 // gy is scaled per (row, chunk) by a power of two taken from the chunk's row maximum
 // (LDS max, one extra barrier per chunk); when a row's scale changes between chunks the
 // wave rescales that row of its accumulators (exact), and the epilogue undoes both.
+// Row statistics (rowstats != nullptr): gx is the gradient that reaches the LayerNorm below
+// this layer, whose backward needs sum_i gx[b,i] and sum_i gx[b,i]*x[b,i] of every row (x of
+// this layer IS that LayerNorm's output).  Both are at hand in the epilogue: every wave adds
+// them up over its 32 inputs (DPP row sums, the two rows of 16 lanes through SGPRs) and
+// writes rowstats[tile][b] = (s1, s2), tile = input / 32; the consumer
+// (pp_split_pack_gy_ln_ranged_kernel, pp_bf3_bwdw.hip) adds the tiles in order.
 // ---------------------------------------------------------------------------
 template <class SC>
 __global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __restrict__ wt,
@@ -29,13 +35,14 @@ __global__ __launch_bounds__(256) void pp_split_pack_wo_kernel(const float* __re
 constexpr int kOC = 8;  // 16-out steps per gy chunk
 
 
-template <class SC, int N, int K, int RM, int VW>
+template <class SC, int N, int K, int RM, int VW, bool STATS>
 __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
                                                const float* __restrict__ gy,
                                                const void* __restrict__ ws, float* __restrict__ gx,
                                                const PPShape& sh, const BasisTab& tab,
                                                const DenseCoord3& dc, int nso, int Ipad,
-                                               unsigned q_off, u32x4* gyL) {
+                                               unsigned q_off, u32x4* gyL,
+                                               float* __restrict__ rowstats) {
   PP_TICK(0)
   using frag = typename SC::frag;
   constexpr int PL = SC::PL;
@@ -269,12 +276,16 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
   }
   const int lastbuf = (nchunk - 1) & 1;
 
-  // epilogue: lane owns input column i0 + r for 16*RM rows
-  if (i < sh.I) {
+  // epilogue: lane owns input column i0 + r for 16*RM rows (with the row sums every lane
+  // goes through it: DPP and readlane want the whole wave, the padded inputs add zeros)
+  const bool own = i < sh.I;
+  if (STATS || own) {
+    const bool stats_on = STATS && i0 < Ipad;  // wave-uniform
     const float chain = (sh.length * dc.inv_w) * sh.out_scale;  // dxi/dx = L/(2/S)
     constexpr int S = Geom3<N, K>::S, stride = Geom3<N, K>::stride;
 #pragma unroll
-    for (int rm = 0; rm < RM; ++rm)
+    for (int rm = 0; rm < RM; ++rm) {
+      float st1 = 0.0f, st2 = 0.0f;  // lane r < 16: the sums of row slot q = r of this half
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = b0 + rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -299,25 +310,48 @@ __device__ __forceinline__ void bwd_x_bf3_body(const float* __restrict__ x,
         }
         if constexpr (SC::kRanged)
           gsum *= rscL[lastbuf][rm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h].y * wsinv;
-        if (row < sh.B) gx[(size_t)row * sh.I + i] = gsum * chain;
+        const float g = gsum * chain;
+        if (own && row < sh.B) gx[(size_t)row * sh.I + i] = g;
+        if constexpr (STATS) if (stats_on) {  // (all 64 lanes are here: the padded inputs add zeros)
+          float a = own ? g : 0.0f, b = own ? g * xq : 0.0f;
+          a = pp_dpp_add<0x128>(a); b = pp_dpp_add<0x128>(b);  // row_ror:8, 4, 2, 1
+          a = pp_dpp_add<0x124>(a); b = pp_dpp_add<0x124>(b);
+          a = pp_dpp_add<0x122>(a); b = pp_dpp_add<0x122>(b);
+          a = pp_dpp_add<0x121>(a); b = pp_dpp_add<0x121>(b);
+          const float a0 = pp_readlane_f(a, 0) + pp_readlane_f(a, 16);
+          const float a1 = pp_readlane_f(a, 32) + pp_readlane_f(a, 48);
+          const float b0s = pp_readlane_f(b, 0) + pp_readlane_f(b, 16);
+          const float b1s = pp_readlane_f(b, 32) + pp_readlane_f(b, 48);
+          if (r == q) {
+            st1 = h ? a1 : a0;
+            st2 = h ? b1s : b0s;
+          }
+        }
       }
+      if constexpr (STATS) if (stats_on && r < 16) {
+        const int row = b0 + rm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < sh.B)
+          reinterpret_cast<float2*>(rowstats)[(size_t)(i0 >> 5) * sh.B + row] = make_float2(st1, st2);
+      }
+    }
   }
   PP_TICK(7)
 }
 
-template <class SC, int N, int K, int RM>
+template <class SC, int N, int K, int RM, bool STATS>
 __global__ __launch_bounds__(256, (RM == 1 && K <= 5) ? 2 : 1) void pp_bwd_x_bf3_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ gy,
                                                            const void* __restrict__ Q,
                                                            float* __restrict__ gx, PPShape sh,
                                                            BasisTab tab, DenseCoord3 dc, int nso,
-                                                           int Ipad, int vw, unsigned q_off) {
+                                                           int Ipad, int vw, unsigned q_off,
+                                                           float* __restrict__ rowstats) {
   extern __shared__ __attribute__((aligned(16))) u32x4 gyL[];  // [2][PL][kOC][2][32*RM] x 16 B
   // vw: widest aligned vector load of a gy row (block-uniform), fixed per body so the
   // staging loads stay straight-line code
-  if (vw == 4) bwd_x_bf3_body<SC, N, K, RM, 4>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
-  else if (vw == 2) bwd_x_bf3_body<SC, N, K, RM, 2>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
-  else bwd_x_bf3_body<SC, N, K, RM, 1>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL);
+  if (vw == 4) bwd_x_bf3_body<SC, N, K, RM, 4, STATS>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL, rowstats);
+  else if (vw == 2) bwd_x_bf3_body<SC, N, K, RM, 2, STATS>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL, rowstats);
+  else bwd_x_bf3_body<SC, N, K, RM, 1, STATS>(x, gy, Q, gx, sh, tab, dc, nso, Ipad, q_off, gyL, rowstats);
 }
 
 }  // namespace
@@ -327,21 +361,36 @@ namespace {
 int nso_of(const PPShape& sh) { return ((sh.O + 31) / 32) * 2; }   // 16-out steps, even
 int ipad_of(const PPShape& sh) { return ((sh.I + 31) / 32) * 32; }
 
-template <class SC, int N, int K, int RM>
-hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, float* gx,
-                            const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
-                            unsigned q_off, hipStream_t st) {
+template <class SC, int N, int K, int RM, bool STATS>
+hipError_t launch_bwd_x_bf3_k(const float* x, const float* gy, const void* ws, float* gx,
+                              const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
+                              unsigned q_off, float* rowstats, hipStream_t st) {
   const size_t lds = (size_t)2 * SC::PL * kOC * 2 * 32 * RM * 16;
   if (lds > 40 * 1024) {  // per call: the attribute is per device, and setting it is cheap
-    hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<SC, N, K, RM>,
+    hipError_t e = hipFuncSetAttribute((const void*)pp_bwd_x_bf3_kernel<SC, N, K, RM, STATS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   const int vw = sh.O % 4 == 0 ? 4 : (sh.O % 2 == 0 ? 2 : 1);
   dim3 grid((sh.B + 32 * RM - 1) / (32 * RM), (ipad_of(sh) + 127) / 128);
-  hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<SC, N, K, RM>), grid, dim3(256), lds, st, x, gy, ws, gx,
-                     sh, tab, dc, nso_of(sh), ipad_of(sh), vw, q_off);
+  hipLaunchKernelGGL((pp_bwd_x_bf3_kernel<SC, N, K, RM, STATS>), grid, dim3(256), lds, st, x, gy,
+                     ws, gx, sh, tab, dc, nso_of(sh), ipad_of(sh), vw, q_off, rowstats);
   return hipGetLastError();
+}
+
+// The row-sum epilogue exists for the kernels PP_METHOD_AUTO runs (fp16x2, 32-row tiles); it is
+// a template switch so that the other instances keep their register budget.
+template <class SC, int N, int K, int RM>
+hipError_t launch_bwd_x_bf3(const float* x, const float* gy, const void* ws, float* gx,
+                            const PPShape& sh, const BasisTab& tab, const DenseCoord3& dc,
+                            unsigned q_off, float* rowstats, hipStream_t st) {
+  if (rowstats) {
+    if constexpr (SC::kRanged && RM == 1)
+      return launch_bwd_x_bf3_k<SC, N, K, RM, true>(x, gy, ws, gx, sh, tab, dc, q_off, rowstats, st);
+    else
+      return hipErrorInvalidValue;
+  }
+  return launch_bwd_x_bf3_k<SC, N, K, RM, false>(x, gy, ws, gx, sh, tab, dc, q_off, nullptr, st);
 }
 
 template <class SC>
@@ -361,7 +410,7 @@ void pack_wo_split(const float* wt, void* ws, unsigned q_off, const PPShape& sh,
 template <class SC>
 hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, float* gx,
                               void* ws, const PPShape& sh, const BasisTab& tab, bool prepacked,
-                              unsigned q_off, hipStream_t st) {
+                              unsigned q_off, float* rowstats, hipStream_t st) {
   DenseCoord3 dc;
   dc.w2 = 2.0f / (float)sh.S;
   dc.inv_w = (float)sh.S / 2.0f;
@@ -381,9 +430,9 @@ hipError_t launch_bwd_x_split(const float* x, const float* gy, const float* wt, 
 #define X(N_, K_)                                                                          \
   if (sh.n == N_ && sh.K == K_) {                                                          \
     if constexpr (K_ <= 5) {                                                               \
-      if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, q_off, st); \
+      if (rm == 2) return launch_bwd_x_bf3<SC, N_, K_, 2>(x, gy, ws, gx, sh, tab, dc, q_off, rowstats, st); \
     }                                                                                      \
-    return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, q_off, st);                \
+    return launch_bwd_x_bf3<SC, N_, K_, 1>(x, gy, ws, gx, sh, tab, dc, q_off, rowstats, st);                \
   }
   PP_BF3_COMBOS(X)
 #undef X
@@ -402,14 +451,19 @@ size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh) {
 
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
                                void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st) {
-  return launch_bwd_x_split<SchemeBf3>(x, gy, wt, gx, ws, sh, tab, false, (unsigned)kWsHeader, st);
+  return launch_bwd_x_split<SchemeBf3>(x, gy, wt, gx, ws, sh, tab, false, (unsigned)kWsHeader,
+                                       nullptr, st);
 }
 
 hipError_t pp_launch_bwd_x_h2(const float* x, const float* gy, const float* wt, float* gx,
                               void* ws, const PPShape& sh, const BasisTab& tab, bool prepacked,
-                              size_t q_off, hipStream_t st) {
-  return launch_bwd_x_split<SchemeH2>(x, gy, wt, gx, ws, sh, tab, prepacked, (unsigned)q_off, st);
+                              size_t q_off, float* rowstats, hipStream_t st) {
+  return launch_bwd_x_split<SchemeH2>(x, gy, wt, gx, ws, sh, tab, prepacked, (unsigned)q_off,
+                                      rowstats, st);
 }
+
+// tiles of 32 inputs the row statistics are written in ([tiles][B] float2)
+int pp_bwd_x_rowstats_tiles(const PPShape& sh) { return ipad_of(sh) / 32; }
 
 size_t pp_h2_bwd_x_packed_bytes(const PPShape& sh) {
   return (size_t)2 * nso_of(sh) * sh.K * ipad_of(sh) * 32;

@@ -152,12 +152,21 @@ bool pp_bf3_bwd_x_supported(const PPShape& sh);
 size_t pp_bf3_bwd_x_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_x_bf3(const float* x, const float* gy, const float* wt, float* gx,
                                void* ws, const PPShape& sh, const BasisTab& tab, hipStream_t st);
+// rowstats (or nullptr): [pp_bwd_x_rowstats_tiles][B] float2 = (sum_i gx, sum_i gx*x) per tile of
+// 32 inputs, for the LayerNorm backward of the layer below (pp_launch_bwd_w_h2_ln)
 hipError_t pp_launch_bwd_x_h2(const float* x, const float* gy, const float* wt, float* gx,
                               void* ws, const PPShape& sh, const BasisTab& tab, bool prepacked,
-                              size_t q_off, hipStream_t st);
+                              size_t q_off, float* rowstats, hipStream_t st);
+int pp_bwd_x_rowstats_tiles(const PPShape& sh);
 bool pp_bf3_bwd_w_supported(const PPShape& sh);
 size_t pp_bf3_bwd_w_workspace_bytes(const PPShape& sh);
 hipError_t pp_launch_bwd_w_bf3(const float* x, const float* gy, float* gwt, void* ws,
                                const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_bwd_w_h2(const float* x, const float* gy, float* gwt, void* ws,
                               const PPShape& sh, const BasisTab& tab, hipStream_t st);
+// the same with the LayerNorm backward of the layer's output folded into the pack pass:
+// g_out = rstd*(gy - m1 - yn*m2) (row means from `ntile` tiles of rowstats), gwt from g_out
+hipError_t pp_launch_bwd_w_h2_ln(const float* x, const float* gy, const float* yn,
+                                 const float* rstd, const float* rowstats, int ntile, float* g_out,
+                                 float* gwt, void* ws, const PPShape& sh, const BasisTab& tab,
+                                 hipStream_t st);

@@ -204,7 +204,10 @@ def forward_raw(x, w_t, spec: LayerSpec, want_seg: bool = False, packed=None):
     return y, seg
 
 
-def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None):
+def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None, row_stats=None):
+    """gx[B,I].  row_stats: a float32 [tiles, B, 2] tensor (tiles = pp_row_stats_tiles(I)) that
+    receives the row sums of gx and gx*x the LayerNorm backward of the layer below needs
+    (pp_backward_input_stats_ws_f32: fp16x2 kernels only)."""
     lib = _lib.load()
     B, I = x.shape
     O = w_t.shape[2]
@@ -220,12 +223,96 @@ def backward_input_raw(x, gy, w_t, spec: LayerSpec, packed=None):
                                                        method)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
     with torch.cuda.device(x.device):
+        if row_stats is not None:
+            rc = lib.pp_backward_input_stats_ws_f32(
+                _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), _ptr(row_stats), _ptr(ws), nbytes, B, I, O,
+                spec.n, spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
+                spec.out_scale, method, _stream(x.device))
+            _lib.check(rc, "pp_backward_input_stats_ws_f32")
+            return gx
         rc = lib.pp_backward_input_ws_f32(
             _ptr(x), _ptr(gy), _ptr(w_t), _ptr(gx), _ptr(ws), nbytes, B, I, O, spec.n,
             spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
             spec.out_scale, method, _stream(x.device))
     _lib.check(rc, "pp_backward_input_ws_f32")
     return gx
+
+
+# LayerNorm backward folded into the backward of the layer below.  A layer whose
+# input IS the output of a fused layer+LayerNorm node (HighOrderMLP.forward says so through
+# `input_is_layer_norm`) lets its backward-input kernel leave the two row sums of gx the
+# LayerNorm backward needs; the node below finds them here, keyed by the gradient tensor it is
+# handed, and runs pp_backward_weight_layer_norm_f32 instead of the LayerNorm-backward kernel +
+# the plain weight gradient.  One slot: the producer's backward is directly followed by the
+# consumer's; anything that does not match (another gradient tensor, an accumulated one, a
+# changed version counter) falls back to the separate kernels.
+#
+# OFF by default: measured on MI355X (cfg2 hidden layer, 16384 rows, profiles/r03_k_ln_fold.txt)
+# the folded pack pass takes 20.5 us against 9.3 (LayerNorm backward) + 8.4 (pack) for the two
+# kernels it replaces -- it reads two tensors and writes two in 128-byte row pieces, 6 MB of
+# them live per XCD against 4 MB of L2 -- and the row-sum epilogue costs the backward-input
+# kernel 1.6 us: the step is 13 us SLOWER with it.  Kept as a tested option
+# (FOLD_LAYER_NORM_BACKWARD = True) because the traffic argument (64 MB instead of 80) would
+# favour it on a layer whose rows are multiples of 128 bytes.
+FOLD_LAYER_NORM_BACKWARD = False
+_input_is_layer_norm = False   # set by HighOrderMLP.forward around the call of such a layer
+_row_stats_slot = None         # (gx, gx._version, x of the producer, stats)
+
+
+def _emit_row_stats(ctx_flag: bool, x, w_t, spec: LayerSpec) -> bool:
+    if not FOLD_LAYER_NORM_BACKWARD or not ctx_flag or spec.bwd_x_method != "auto" or \
+            x.shape[0] == 0:
+        return False
+    I, _, O = w_t.shape
+    return bool(_lib.load().pp_backward_input_stats_supported(
+        x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length))
+
+
+def _backward_input_with_stats(x, gy, w_t, spec: LayerSpec, packed, emit: bool):
+    """backward_input_raw; with `emit` the row sums go to the slot for the node below."""
+    global _row_stats_slot
+    if not emit or not _emit_row_stats(True, x, w_t, spec):
+        return backward_input_raw(x, gy, w_t, spec, packed=packed)
+    B, I = x.shape
+    stats = torch.empty(_lib.load().pp_row_stats_tiles(I), B, 2, device=x.device,
+                        dtype=torch.float32)
+    gx = backward_input_raw(x, gy, w_t, spec, packed=packed, row_stats=stats)
+    _row_stats_slot = (gx, gx._version, x, stats)
+    return gx
+
+
+def _take_row_stats(gy, y):
+    """The row sums left for gradient `gy` at LayerNorm output `y`, or None; empties the slot."""
+    global _row_stats_slot
+    slot, _row_stats_slot = _row_stats_slot, None
+    if slot is None:
+        return None
+    gx, version, x_above, stats = slot
+    if gx.data_ptr() != gy.data_ptr() or gx.shape != gy.shape or gx._version != version or \
+            gy._version != version or x_above.data_ptr() != y.data_ptr() or \
+            x_above.shape != y.shape or stats.device != y.device:
+        return None
+    return stats
+
+
+def backward_weight_layer_norm_raw(x, gy, y, rstd, stats, w_shape_t, spec: LayerSpec, out=None):
+    """(g, gw_t): g[B,O] = LayerNorm backward of gy at output y (row means from `stats`), gw_t
+    [I,K,O] the weight gradient taken from g -- one pack pass instead of two kernels."""
+    lib = _lib.load()
+    B, I = x.shape
+    I2, K, O = w_shape_t
+    gw_t = out if out is not None else torch.empty(I2, K, O, device=x.device, dtype=torch.float32)
+    g = torch.empty_like(y)
+    nbytes = lib.pp_workspace_bytes(B, I, O, spec.n, spec.segments, int(spec.discontinuous),
+                                    spec.length, _lib.BWD_W_FP16X2)
+    ws = torch.empty(max(nbytes, 16), device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        rc = lib.pp_backward_weight_layer_norm_f32(
+            _ptr(x), _ptr(gy), _ptr(y), _ptr(rstd), _ptr(stats), stats.shape[0], _ptr(g),
+            _ptr(gw_t), _ptr(ws), nbytes, B, I, O, spec.n, spec.segments, int(spec.discontinuous),
+            spec.length, spec.node_array(), spec.out_scale, _lib.BWD_W_FP16X2, _stream(x.device))
+    _lib.check(rc, "pp_backward_weight_layer_norm_f32")
+    return g, gw_t
 
 
 # Gradient buffers assigned ahead of the backward (parallel.FlatGradBucket): storage pointer of a
@@ -302,6 +389,7 @@ class PiecewisePolyFunction(torch.autograd.Function):
         # the pre-split weights serve this step's backward-input too (w cannot change in
         # between: autograd checks the saved tensor's version)
         ctx.packed = packed if ctx.needs_input_grad[0] else None
+        ctx.emit_stats = _input_is_layer_norm
         ctx.save_for_backward(x, w)
         return y
 
@@ -314,12 +402,12 @@ class PiecewisePolyFunction(torch.autograd.Function):
             gy = gy.float()
         w_t = kernel_layout(w.detach())
         gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = backward_input_raw(x, gy, w_t, spec, packed=ctx.packed)
         if ctx.needs_input_grad[1]:
             gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec,
                                        out=_assigned_grad(w, w_t.shape))
             gw = gw_t.permute(2, 0, 1)  # logical [O,I,K]; same strides as the module's parameter
+        if ctx.needs_input_grad[0]:  # last: its row sums wait in the slot for the node below
+            gx = _backward_input_with_stats(x, gy, w_t, spec, ctx.packed, ctx.emit_stats)
         return gx, gw, None
 
 
@@ -377,6 +465,7 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         _lib.check(rc, "pp_forward_layer_norm_f32")
         ctx.spec = spec
         ctx.packed = packed if ctx.needs_input_grad[0] else None
+        ctx.emit_stats = _input_is_layer_norm
         ctx.save_for_backward(x, w, y, rstd)
         return y
 
@@ -389,18 +478,28 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         if gy.dtype != torch.float32:
             gy = gy.float()
         B, O = y.shape
-        g = torch.empty_like(y)  # gradient w.r.t. the layer's (never stored) raw output
-        with torch.cuda.device(y.device):
-            rc = lib.pp_layer_norm_bwd_f32(_ptr(y), _ptr(gy), _ptr(rstd), _ptr(g), B, O,
-                                           _stream(y.device))
-        _lib.check(rc, "pp_layer_norm_bwd_f32")
         w_t = kernel_layout(w.detach())
         gx = gw = None
+        # the node above left the row sums of gy: the LayerNorm backward rides in the pass that
+        # splits the gradient for the weight-gradient kernel (no LayerNorm-backward kernel)
+        stats = _take_row_stats(gy, y)
+        if stats is not None and ctx.needs_input_grad[1] and spec.bwd_w_method == "auto" and \
+                lib.pp_backward_weight_layer_norm_supported(
+                    B, x.shape[1], O, spec.n, spec.segments, int(spec.discontinuous), spec.length):
+            g, gw_t = backward_weight_layer_norm_raw(x, gy, y, rstd, stats, tuple(w_t.shape), spec,
+                                                     out=_assigned_grad(w, w_t.shape))
+            gw = gw_t.permute(2, 0, 1)
+        else:
+            g = torch.empty_like(y)  # gradient w.r.t. the layer's (never stored) raw output
+            with torch.cuda.device(y.device):
+                rc = lib.pp_layer_norm_bwd_f32(_ptr(y), _ptr(gy), _ptr(rstd), _ptr(g), B, O,
+                                               _stream(y.device))
+            _lib.check(rc, "pp_layer_norm_bwd_f32")
+            if ctx.needs_input_grad[1]:
+                gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
+                                         out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
         if ctx.needs_input_grad[0]:
-            gx = backward_input_raw(x, g, w_t, spec, packed=ctx.packed)
-        if ctx.needs_input_grad[1]:
-            gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
-                                     out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
+            gx = _backward_input_with_stats(x, g, w_t, spec, ctx.packed, ctx.emit_stats)
         return gx, gw, None, None
 
 

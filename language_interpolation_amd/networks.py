@@ -82,24 +82,34 @@ class HighOrderMLP(nn.Module):
             # the weights of all matrix-core layers are pre-split for this step in two launches
             PF.prepack_layers([m for m in mods if hasattr(m, "forward_layer_norm")], x.shape[0])
         i = 0
-        while i < len(mods):
-            m = mods[i]
-            if i + 1 < len(mods) and isinstance(mods[i + 1], LazyLayerNormLastDim) and \
-                    hasattr(m, "forward_layer_norm"):
-                fused = m.forward_layer_norm(x, LazyLayerNormLastDim.EPS)
-                if fused is not None:
-                    x = fused
-                    i += 2
-                    continue
-            if i + 1 < len(mods) and isinstance(mods[i + 1], MaxAbsNormalizationLast) and \
-                    hasattr(m, "forward_max_abs"):
-                fused = m.forward_max_abs(x, mods[i + 1]._eps)
-                if fused is not None:
-                    x = fused
-                    i += 2
-                    continue
-            x = m(x)
-            i += 1
+        # after_ln: x is the output of a fused layer+LayerNorm node and feeds the next polynomial
+        # layer directly -- that layer's backward-input then leaves the row sums with which the
+        # LayerNorm backward rides in the weight-gradient pass of the layer below (PF._row_stats_slot)
+        after_ln = False
+        try:
+            while i < len(mods):
+                m = mods[i]
+                PF._input_is_layer_norm = after_ln and hasattr(m, "forward_layer_norm")
+                after_ln = False
+                if i + 1 < len(mods) and isinstance(mods[i + 1], LazyLayerNormLastDim) and \
+                        hasattr(m, "forward_layer_norm"):
+                    fused = m.forward_layer_norm(x, LazyLayerNormLastDim.EPS)
+                    if fused is not None:
+                        x = fused
+                        after_ln = True
+                        i += 2
+                        continue
+                if i + 1 < len(mods) and isinstance(mods[i + 1], MaxAbsNormalizationLast) and \
+                        hasattr(m, "forward_max_abs"):
+                    fused = m.forward_max_abs(x, mods[i + 1]._eps)
+                    if fused is not None:
+                        x = fused
+                        i += 2
+                        continue
+                x = m(x)
+                i += 1
+        finally:
+            PF._input_is_layer_norm = False
         # the pre-split buffers belong to this step only (each layer's autograd node holds its
         # own reference for the backward): a later call of self.model / a sub-layer must not find
         # them after an optimizer that writes the weights through raw pointers or .data

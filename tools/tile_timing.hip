@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
       {8, 2, 1, 0, "R=1024, no input split"},
       {8, 2, 2, 0, "R=1024, 2 splits"},
       {8, 2, 8, 0, "R=1024, 8 splits"},
+      {4, 2, 1, 0, "R=512, 1 split"},
       {4, 2, 2, 0, "R=512, 2 splits"},
       {4, 2, 4, 0, "R=512, 4 splits"},
       {4, 1, 1, 0, "R=256, 1 split"},
