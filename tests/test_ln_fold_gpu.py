@@ -217,3 +217,64 @@ def test_fold_is_skipped_when_the_gradient_is_not_the_one_the_sums_belong_to(mon
     b = run(False)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_fold_entry_points_on_random_shapes():
+    """Seeded sweep over ragged shapes (rows off the 32 / 512 boundaries, inputs and outs off the
+    tile widths): every shape the library says it supports gives bit-identical gx, tile sums that
+    add up, and g / gw_t within the bar of the separate kernels."""
+    import random
+    from language_interpolation_amd import _lib
+    PF = _pf()
+    lib = _lib.load()
+    rng = random.Random(77)
+    done_x = done_w = 0
+    for _ in range(200):
+        n = rng.choice([2, 3, 4, 5])
+        disc = rng.random() < 0.3
+        S = rng.choice([1, 2, 2, 4]) if not disc else rng.choice([1, 2])
+        K = n * S if disc else (n - 1) * S + 1
+        if K > 8:
+            continue
+        B = rng.choice([rng.randint(256, 1100), rng.randint(4096, 9000), 8192, 4097])
+        I = rng.choice([32, 33, 64, 100, 250, rng.randint(32, 300)])
+        O = rng.choice([32, 70, 128, 129, 250, rng.randint(32, 300)])
+        x, w, gy = make_inputs(B, I, O, n, S, disc, rng.choice(["normal", "uniform"]),
+                               seed=rng.randint(0, 1 << 30))
+        spec = PF.make_spec(n, S, disc)
+        xd, gyd = x.cuda(), gy.cuda()
+        w_t = w.cuda().permute(1, 2, 0).contiguous()
+        if lib.pp_backward_input_stats_supported(B, I, O, n, S, int(disc), 2.0) and done_x < 25:
+            tiles = lib.pp_row_stats_tiles(I)
+            stats = torch.full((tiles, B, 2), float("nan"), device="cuda")
+            gx = PF.backward_input_raw(xd, gyd, w_t, spec, row_stats=stats)
+            gx0 = PF.backward_input_raw(xd, gyd, w_t, spec)
+            assert torch.equal(gx, gx0), (B, I, O, n, S, disc)
+            assert torch.isfinite(stats).all(), (B, I, O, n, S, disc)
+            s = stats.double().sum(dim=0)
+            scale = gx.double().abs().sum(dim=1).clamp_min(1e-30)
+            xmax = xd.abs().max().item() + 1.0
+            assert ((s[:, 0] - gx.double().sum(dim=1)).abs() / scale).max().item() <= 1e-6
+            assert ((s[:, 1] - (gx.double() * xd.double()).sum(dim=1)).abs() / scale).max().item() \
+                <= 1e-6 * xmax
+            done_x += 1
+        if lib.pp_backward_weight_layer_norm_supported(B, I, O, n, S, int(disc), 2.0) and done_w < 25:
+            raw, _ = PF.forward_raw(xd, w_t, spec)
+            yn = torch.empty_like(raw)
+            rstd = torch.empty(B, device="cuda")
+            assert lib.pp_layer_norm_fwd_f32(PF._ptr(raw), PF._ptr(yn), PF._ptr(rstd), B, O, 1e-5,
+                                             PF._stream(raw.device)) == 0
+            tiles = lib.pp_row_stats_tiles(O)
+            pad = tiles * 32 - O
+            s1 = torch.nn.functional.pad(gyd, (0, pad)).view(B, tiles, 32).sum(dim=2)
+            s2 = torch.nn.functional.pad(gyd * yn, (0, pad)).view(B, tiles, 32).sum(dim=2)
+            stats = torch.stack((s1.t(), s2.t()), dim=2).contiguous()
+            g, gw = PF.backward_weight_layer_norm_raw(xd, gyd, yn, rstd, stats, tuple(w_t.shape), spec)
+            g0 = torch.empty_like(raw)
+            assert lib.pp_layer_norm_bwd_f32(PF._ptr(yn), PF._ptr(gyd), PF._ptr(rstd), PF._ptr(g0),
+                                             B, O, PF._stream(raw.device)) == 0
+            gw0 = PF.backward_weight_raw(xd, g0, tuple(w_t.shape), spec)
+            assert rel_err(g.cpu(), g0.cpu()) <= 4e-6, (B, I, O, n, S, disc)
+            assert rel_err(gw.cpu(), gw0.cpu()) <= TOL, (B, I, O, n, S, disc)
+            done_w += 1
+    assert done_x >= 15 and done_w >= 8, (done_x, done_w)
