@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void pp_bwdx_tile_kernel(
   dma_wait((nbuf - 2) * cnt);
   __syncthreads();
   int buf = 0, bnew = nbuf - 1;
-  float pend[UW][4];
+  float pend[UW][8];
   for (int i = i_lo; i < i_hi; ++i) {
     int rc[UW][P];
 #pragma unroll
@@ -471,12 +471,24 @@ __global__ __launch_bounds__(64 * NW) void pp_bwdx_tile_kernel(
           if constexpr (BS == 4) r += res[m][2] + res[m][3];
           v = fmaf(__int_as_float(rc[u][1 + m]), r, v);
         }
-        // four inputs' values a store (i_lo and I are multiples of 4)
-        pend[u][(i - i_lo) & 3] = v;
+        // eight inputs' values go out together, as two 16-byte stores side by side: a whole
+        // 32-byte sector per lane (groups by absolute input index; i_lo, i_hi and I are multiples
+        // of 4, so a split may begin or end on half a group, which goes out as one store).  With
+        // one 16-byte store per four inputs every sector went to memory half-written --
+        // WRITE_SIZE 104.7 MB for 52.4 MB of partial gx (profiles/r03_k_pmc_cfg3_quirk_16384.json).
+        const int slot = i & 7;
+        pend[u][slot] = v;
         const int row = row0 + u * 64 + lane;
-        if (((i - i_lo) & 3) == 3 && row < sh.B)
-          *reinterpret_cast<float4*>(dst + (size_t)row * sh.I + (i - 3)) =
-              make_float4(pend[u][0], pend[u][1], pend[u][2], pend[u][3]);
+        if (row < sh.B) {
+          if (slot == 7) {
+            float4* q = reinterpret_cast<float4*>(dst + (size_t)row * sh.I + (i - 7));
+            if (i - i_lo >= 7) q[0] = make_float4(pend[u][0], pend[u][1], pend[u][2], pend[u][3]);
+            q[1] = make_float4(pend[u][4], pend[u][5], pend[u][6], pend[u][7]);
+          } else if (slot == 3 && i + 1 == i_hi) {  // the split ends on half a group
+            *reinterpret_cast<float4*>(dst + (size_t)row * sh.I + (i - 3)) =
+                make_float4(pend[u][0], pend[u][1], pend[u][2], pend[u][3]);
+          }
+        }
       }
     }
     dma_wait(i + nbuf - 1 < i_hi ? (nbuf - 2) * cnt : 0);
@@ -685,7 +697,7 @@ hipError_t pp_launch_bwd_x_tile(const float* x, const float* gy, const float* wt
                                 const PPShape& sh, const BasisTab& tab, hipStream_t st) {
   TilePlan p = tile_plan(sh);
   if (!p.ok || sh.n < 2 || sh.I % 4 != 0) return hipErrorInvalidValue;
-  p.per_split = (p.per_split + 3) & ~3;  // the kernel stores four inputs' values at a time
+  p.per_split = (p.per_split + 3) & ~3;  // the kernel stores four or eight inputs' values at a time
   p.nsplit = (sh.I + p.per_split - 1) / p.per_split;
   int32_t* rec = static_cast<int32_t*>(ws);
   const bool direct = p.nchunk == 1;
