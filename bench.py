@@ -170,9 +170,9 @@ def roofline_for_hidden_layer(B, dev):
     # --pmc (separate passes; profiles/*_traffic.json says how), valid for the shape and
     # method it was taken on (weight gradient and backward-input, fp16x2, 16384 rows)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_k_traffic.json")
     if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_i_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if B == 16384 and os.path.exists(tpath):
         with open(tpath) as f:
             measured = json.load(f)
