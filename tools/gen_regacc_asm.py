@@ -299,6 +299,7 @@ X_NODMA = "--x-nodma" in sys.argv
 X_NOLSHR = "--x-nolshr" in sys.argv
 X_NOIDX = "--x-noidx" in sys.argv
 READ1 = "--read1" in sys.argv   # developer variant: one ds_read_b32 a row instead of ds_read2st64_b32 a pair
+TMPIDX = "--tmpidx" in sys.argv  # developer variant: index bytes shifted into rotating temporaries three rows ahead
 
 
 def body_lds1(KMAX):
@@ -388,6 +389,21 @@ def body_lds1(KMAX):
             # the 8 rows of this half: bytes of the register pair s[lo:lo+1]; one 64-bit shift
             # moves the next byte of BOTH registers down, so the rows go 0,4,1,5,2,6,3,7
             lo = IDX0 + 2 * h
+            if TMPIDX:
+                # rows in natural order; byte r % 4 of register lo + r // 4 goes through an
+                # independent 32-bit shift into s53..s55, issued three rows before its use
+                def shift(r):
+                    if r < 8 and r % 4:
+                        a(f"s_lshr_b32 s{52 + r % 4}, s{lo + r // 4}, {8 * (r % 4)}")
+                shift(1)
+                shift(2)
+                for r in range(8):
+                    reg = lo + r // 4 if r % 4 == 0 else 52 + r % 4
+                    if h or r:
+                        a(f"s_set_gpr_idx_idx s{reg}")
+                    a(f"v_add_f32 v{ACC0}, v{cur + r}, v{ACC0}")
+                    shift(r + 3)
+                continue
             for j in range(4):
                 for w in range(2):
                     r = 4 * w + j
