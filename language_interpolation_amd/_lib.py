@@ -89,6 +89,11 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
          c_float, _P, c_float, c_int, _P],
     ),
+    "pp_grid_table_supported": (c_int, [c_int] * 5 + [c_float, c_int]),
+    "pp_grid_table_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float,
+                                  c_int, _P]),
+    "pp_grid_table_grad_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P,
+                                       c_float, c_int, _P]),
     "pp_workspace_bytes": (c_size_t, [c_int] * 6 + [c_float, c_int]),
     "pp_backward_weight_f32": (
         c_int,

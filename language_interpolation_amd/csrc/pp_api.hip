@@ -106,7 +106,7 @@ bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >
 
 extern "C" {
 
-int pp_version(void) { return 301; }  // round 3: PP_FWD_TILE, PP_BWD_X_TILE, pp_forward_max_abs_ws_f32, regacc in parts, LayerNorm fold
+int pp_version(void) { return 302; }  // round 3: PP_FWD_TILE, PP_BWD_X_TILE, pp_forward_max_abs_ws_f32, regacc in parts, LayerNorm fold, grid tables
 
 const char* pp_error_string(int code) {
   switch (code) {
@@ -515,6 +515,44 @@ int pp_backward_weight_layer_norm_f32(const float* x, const float* gy, const flo
   make_basis(tab, n, length, nodes);
   return hip_rc(pp_launch_bwd_w_h2_ln(x, gy, y_norm, rstd, row_stats, stats_tiles, g_out, gw_t,
                                       workspace, sh, tab, (hipStream_t)stream));
+}
+
+int pp_grid_table_supported(int I, int O, int n, int S, int discontinuous, float length,
+                            int points) {
+  PPShape sh;
+  if (make_shape(sh, 1, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
+  PPShape tsh;  // the table layer must itself be a valid layer
+  if (make_shape(tsh, 1, I, O, 1, points, 1, length, 1.0f) != PP_OK) return 0;
+  return pp_grid_table_supported(sh, points) ? 1 : 0;
+}
+
+int pp_grid_table_f32(const float* w_t, float* table, int I, int O, int n, int S, int discontinuous,
+                      float length, const float* nodes, float out_scale, int points,
+                      void* stream) {
+  if (!w_t || !table) return PP_ERR_NULL;
+  if (!aligned16(w_t) || !aligned16(table)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, 1, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (!pp_grid_table_supported(sh, points)) return PP_ERR_METHOD;
+  if ((long)I * points >= (1L << 31)) return PP_ERR_RANGE;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_grid_table(w_t, table, sh, tab, points, (hipStream_t)stream));
+}
+
+int pp_grid_table_grad_f32(const float* g_table, float* gw_t, int I, int O, int n, int S,
+                           int discontinuous, float length, const float* nodes, float out_scale,
+                           int points, void* stream) {
+  if (!g_table || !gw_t) return PP_ERR_NULL;
+  if (!aligned16(g_table) || !aligned16(gw_t)) return PP_ERR_ALIGN;
+  PPShape sh;
+  int rc = make_shape(sh, 1, I, O, n, S, discontinuous, length, out_scale);
+  if (rc != PP_OK) return rc;
+  if (!pp_grid_table_supported(sh, points)) return PP_ERR_METHOD;
+  BasisTab tab;
+  make_basis(tab, n, length, nodes);
+  return hip_rc(pp_launch_grid_table_grad(g_table, gw_t, sh, tab, points, (hipStream_t)stream));
 }
 
 int pp_transpose_w_f32(const float* w, float* w_t, int O, int I, int K, void* stream) {

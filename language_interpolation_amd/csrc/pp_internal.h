@@ -35,6 +35,13 @@ hipError_t pp_launch_bwd_weight_atomic(const float* x, const float* gy, float* g
                                        const PPShape& sh, const BasisTab& tab, hipStream_t st);
 hipError_t pp_launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);
 
+// ---- table form of a layer whose inputs lie on a uniform grid of P points (pp_table.hip) ----
+bool pp_grid_table_supported(const PPShape& sh, int P);
+hipError_t pp_launch_grid_table(const float* wt, float* T, const PPShape& sh, const BasisTab& tab,
+                                int P, hipStream_t st);
+hipError_t pp_launch_grid_table_grad(const float* GT, float* gwt, const PPShape& sh,
+                                     const BasisTab& tab, int P, hipStream_t st);
+
 // ---- LDS-staged slab path for many-segment layers with few inputs (pp_slab.hip) ----
 bool pp_slab_fwd_supported(const PPShape& sh);  // the kernel can run this shape
 bool pp_slab_fwd_preferred(const PPShape& sh);  // ... and measured faster than the gather kernel

@@ -46,6 +46,10 @@ class LayerSpec:
     bwd_x_method: str = "auto"
     bwd_w_method: str = "auto"
     nodes: Tuple[float, ...] = field(default=())
+    # > 0: the caller states that every input is one of `input_grid` points (c + 1/2)*2/P - 1
+    # (P = 128: the character encoding (c - 63.5)/64 of single_text_dataset.py:15-16); forward and
+    # weight gradient then run the layer in its table form (csrc/pp_table.hip).  Not checked.
+    input_grid: int = 0
 
     def node_array(self):
         vals = self.nodes if self.nodes else tuple(chebyshev_lobatto(self.n, self.length).tolist())
@@ -369,6 +373,55 @@ def segment_ids(x: torch.Tensor, segments: int, length: float = 2.0) -> torch.Te
     return seg
 
 
+def table_spec(spec: LayerSpec) -> LayerSpec:
+    """The piecewise-constant layer (n = 1, one segment per grid point) a layer with
+    `input_grid` runs as; out_scale is folded into the table."""
+    return make_spec(1, spec.input_grid, True, spec.length)
+
+
+def grid_table(w_t, spec: LayerSpec):
+    """T[I, P, O] = out_scale * sum_j l_j(xi(x_c)) * w_t[i, s(x_c)*stride + j, :] for the P grid
+    points x_c of spec.input_grid (pp_grid_table_f32)."""
+    lib = _lib.load()
+    I, K, O = w_t.shape
+    T = torch.empty(I, spec.input_grid, O, device=w_t.device, dtype=torch.float32)
+    with torch.cuda.device(w_t.device):
+        rc = lib.pp_grid_table_f32(_ptr(w_t), _ptr(T), I, O, spec.n, spec.segments,
+                                   int(spec.discontinuous), spec.length, spec.node_array(),
+                                   spec.out_scale, spec.input_grid, _stream(w_t.device))
+    _lib.check(rc, "pp_grid_table_f32")
+    return T
+
+
+def grid_table_grad(g_table, w_shape_t, spec: LayerSpec, out=None):
+    """gw_t[I, K, O] from the gradient of the table (pp_grid_table_grad_f32); into `out` if given."""
+    lib = _lib.load()
+    I, K, O = w_shape_t
+    gw_t = out if out is not None else torch.empty(I, K, O, device=g_table.device,
+                                                   dtype=torch.float32)
+    with torch.cuda.device(g_table.device):
+        rc = lib.pp_grid_table_grad_f32(_ptr(g_table), _ptr(gw_t), I, O, spec.n, spec.segments,
+                                        int(spec.discontinuous), spec.length, spec.node_array(),
+                                        spec.out_scale, spec.input_grid, _stream(g_table.device))
+    _lib.check(rc, "pp_grid_table_grad_f32")
+    return gw_t
+
+
+def _table_weight_gradient(x, g, w, w_t, spec: LayerSpec):
+    """Weight gradient of a layer in table form: one indexed add per (row, input) into the
+    table's gradient, then the map back to the layer's own basis."""
+    I, K, O = w_t.shape
+    g_table = backward_weight_raw(x, g, (I, spec.input_grid, O), table_spec(spec))
+    return grid_table_grad(g_table, (I, K, O), spec, out=_assigned_grad(w, w_t.shape))
+
+
+def on_input_grid(x: torch.Tensor, points: int = 128) -> bool:
+    """True when every element of x is one of the `points` grid values (a debugging aid: the
+    layers do not call it; it synchronises)."""
+    c = (x.double() + 1.0) * (points / 2.0) - 0.5
+    return bool(((c == c.round()) & (c >= 0) & (c <= points - 1)).all().item())
+
+
 class PiecewisePolyFunction(torch.autograd.Function):
     """y = piecewise_poly(x[B,I], w[O,I,K]) with hand-written HIP forward/backward."""
 
@@ -381,10 +434,15 @@ class PiecewisePolyFunction(torch.autograd.Function):
         _require_gpu(w, "w")
         x = x.contiguous()
         w_t = kernel_layout(w.detach())
-        packed = pack_weights(w_t, spec, x.shape[0], version=w._version)
-        fwd_packed = packed if packed is not None and _fwd_takes_packed(w_t, spec, x.shape[0]) \
-            else None
-        y, _ = forward_raw(x, w_t, spec, packed=fwd_packed)
+        if spec.input_grid and x.shape[0]:
+            # inputs on a grid (the caller's statement): the layer in its table form
+            packed = None
+            y, _ = forward_raw(x, grid_table(w_t, spec), table_spec(spec))
+        else:
+            packed = pack_weights(w_t, spec, x.shape[0], version=w._version)
+            fwd_packed = packed if packed is not None and \
+                _fwd_takes_packed(w_t, spec, x.shape[0]) else None
+            y, _ = forward_raw(x, w_t, spec, packed=fwd_packed)
         ctx.spec = spec
         # the pre-split weights serve this step's backward-input too (w cannot change in
         # between: autograd checks the saved tensor's version)
@@ -403,8 +461,11 @@ class PiecewisePolyFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         gx = gw = None
         if ctx.needs_input_grad[1]:
-            gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec,
-                                       out=_assigned_grad(w, w_t.shape))
+            if spec.input_grid and x.shape[0]:
+                gw_t = _table_weight_gradient(x, gy, w, w_t, spec)
+            else:
+                gw_t = backward_weight_raw(x, gy, tuple(w_t.shape), spec,
+                                           out=_assigned_grad(w, w_t.shape))
             gw = gw_t.permute(2, 0, 1)  # logical [O,I,K]; same strides as the module's parameter
         if ctx.needs_input_grad[0]:  # last: its row sums wait in the slot for the node below
             gx = _backward_input_with_stats(x, gy, w_t, spec, ctx.packed, ctx.emit_stats)
@@ -422,6 +483,8 @@ def layer_norm_fusable(x: torch.Tensor, w: torch.Tensor, spec: LayerSpec) -> boo
             not x.is_cuda or x.shape[0] == 0:
         return False
     O, I, _ = w.shape
+    if spec.input_grid:  # the table layer's kernels decide
+        spec = table_spec(spec)
     return bool(_lib.load().pp_forward_layer_norm_supported(
         x.shape[0], I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length))
 
@@ -442,15 +505,20 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
         w_t = kernel_layout(w.detach())
         B, I = x.shape
         O = w_t.shape[2]
-        mode = lib.pp_forward_layer_norm_supported(B, I, O, spec.n, spec.segments,
-                                                   int(spec.discontinuous), spec.length)
-        packed = pack_weights(w_t, spec, B, version=w._version)  # (the backward-input's too)
+        # fs / fw: the layer the forward kernel runs -- the layer itself, or its table form
+        fs, fw = spec, w_t
+        if spec.input_grid:
+            fs, fw = table_spec(spec), grid_table(w_t, spec)
+        mode = lib.pp_forward_layer_norm_supported(B, I, O, fs.n, fs.segments,
+                                                   int(fs.discontinuous), fs.length)
+        packed = None if spec.input_grid else \
+            pack_weights(w_t, spec, B, version=w._version)  # (the backward-input's too)
         if mode == 0 or (mode == 1 and packed is None):
             raise _lib.PPHipError("fused layer+LayerNorm called on a layer that has no such kernel")
         fwd_packed = packed if mode == 1 else None
         if mode == 3:  # row-tile kernel: its scratch goes in through the same argument
             nbytes = lib.pp_forward_layer_norm_workspace_bytes(
-                B, I, O, spec.n, spec.segments, int(spec.discontinuous), spec.length)
+                B, I, O, fs.n, fs.segments, int(fs.discontinuous), fs.length)
             fwd_packed = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         y = torch.empty(B, O, device=x.device, dtype=torch.float32)
         rstd = torch.empty(B, device=x.device, dtype=torch.float32)
@@ -458,10 +526,10 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
             # mode 2: no packed weights -> the gather kernel with whole rows per wave;
             # mode 3: the row-tile kernel, normalisation in the kernel that sums its partials
             rc = lib.pp_forward_layer_norm_f32(
-                _ptr(x), _ptr(w_t), _ptr(y), _ptr(rstd), _ptr(fwd_packed),
+                _ptr(x), _ptr(fw), _ptr(y), _ptr(rstd), _ptr(fwd_packed),
                 fwd_packed.numel() if fwd_packed is not None else 0, B, I, O,
-                spec.n, spec.segments, int(spec.discontinuous), spec.length, spec.node_array(),
-                spec.out_scale, eps, _stream(x.device))
+                fs.n, fs.segments, int(fs.discontinuous), fs.length, fs.node_array(),
+                fs.out_scale, eps, _stream(x.device))
         _lib.check(rc, "pp_forward_layer_norm_f32")
         ctx.spec = spec
         ctx.packed = packed if ctx.needs_input_grad[0] else None
@@ -496,8 +564,11 @@ class PiecewisePolyLayerNormFunction(torch.autograd.Function):
                                                _stream(y.device))
             _lib.check(rc, "pp_layer_norm_bwd_f32")
             if ctx.needs_input_grad[1]:
-                gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
-                                         out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
+                if spec.input_grid:
+                    gw = _table_weight_gradient(x, g, w, w_t, spec).permute(2, 0, 1)
+                else:
+                    gw = backward_weight_raw(x, g, tuple(w_t.shape), spec,
+                                             out=_assigned_grad(w, w_t.shape)).permute(2, 0, 1)
         if ctx.needs_input_grad[0]:
             gx = _backward_input_with_stats(x, g, w_t, spec, ctx.packed, ctx.emit_stats)
         return gx, gw, None, None

@@ -90,9 +90,32 @@ class _Piecewise(nn.Module):
         return PF.segment_ids(x, self._segments, self._length).long()
 
     def set_methods(self, fwd: str = "auto", bwd_x: str = "auto", bwd_w: str = "auto"):
-        self._spec = PF.make_spec(
+        import dataclasses
+        self._spec = dataclasses.replace(PF.make_spec(
             self._n, self._segments, self._discontinuous, self._length, self.rescale_output,
-            self.in_features, fwd, bwd_x, bwd_w)
+            self.in_features, fwd, bwd_x, bwd_w), input_grid=self._spec.input_grid)
+        return self
+
+    def assume_input_grid(self, points: int = 128):
+        """State that every input of this layer is one of `points` grid values
+        (c + 1/2) * 2/points - 1 -- for points = 128 the character encoding (c - 63.5)/64 of the
+        reference's datasets (single_text_dataset.py:15-16), i.e. what every first layer sees.
+        Forward and weight gradient then run the layer in its table form (one table row
+        gathered / one indexed add per (row, input) instead of n; csrc/pp_table.hip): same
+        results up to fp32 summation order, 36 -> 22 us forward + LayerNorm and 37 -> 28 us weight
+        gradient for the 16 -> 250 input layer at 16384 rows.  The inputs are NOT checked
+        (functional.on_input_grid does, for debugging); points = 0 switches it off."""
+        import dataclasses
+        from . import _lib
+        if points:
+            if self.periodicity is not None:
+                raise ValueError("assume_input_grid: a periodic layer folds its inputs off the grid")
+            if not _lib.load().pp_grid_table_supported(
+                    self.in_features, self.out_features, self._n, self._segments,
+                    int(self._discontinuous), self._length, int(points)):
+                raise ValueError(f"assume_input_grid: no table form for points={points}, "
+                                 f"length={self._length} (needs a power of two <= 128, length 2)")
+        self._spec = dataclasses.replace(self._spec, input_grid=int(points))
         return self
 
     def _prepare(self, x: Tensor) -> Tensor:
