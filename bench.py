@@ -83,9 +83,12 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=20,
-               prepacked=False):
+               prepacked=False, table=0):
     """Seconds per launch of the three entry points of one layer (auto methods, preallocated
-    outputs and workspaces: the timed region is exactly the library's launches)."""
+    outputs and workspaces: the timed region is exactly the library's launches).
+    table = P > 0: a first layer on character inputs in its table form (include/pp_hip.h,
+    pp_grid_table_f32): forward = table build + the n = 1 forward on it, weight gradient = the
+    n = 1 weight gradient + the map back to the layer's basis."""
     from language_interpolation_amd import _lib
     from language_interpolation_amd import functional as PF
 
@@ -141,6 +144,25 @@ def time_layer(B, disc, n, S, I, O, dev, dist_kind="normal", first=False, iters=
         def bwd_x():  # noqa: F811
             lib.pp_backward_input_ws_f32(P(x), P(gy), P(w_t), P(gx), P(packed), pk, B, I, O, n, S,
                                          d, 2.0, nodes, 1.0, _lib.BWD_X_FP16X2 | PRE, st)
+    if table:
+        T = torch.empty(I, table, O, device=dev)
+        GT = torch.empty(I, table, O, device=dev)
+        tfb = lib.pp_forward_workspace_bytes(B, I, O, 1, table, 1, 2.0, 0)
+        tfws = torch.empty(max(tfb, 16), dtype=torch.uint8, device=dev)
+        twb = lib.pp_workspace_bytes(B, I, O, 1, table, 1, 2.0, 0)
+        tws = torch.empty(max(twb, 16), dtype=torch.uint8, device=dev)
+        n1 = PF.make_spec(1, table, True).node_array()
+        methods = [lib.pp_auto_method(p, B, I, O, 1, table, 1, 2.0) for p in range(3)]
+
+        def fwd():  # noqa: F811
+            lib.pp_grid_table_f32(P(w_t), P(T), I, O, n, S, d, 2.0, nodes, 1.0, table, st)
+            lib.pp_forward_ws_f32(P(x), P(T), P(y), None, P(tfws), tfb, B, I, O, 1, table, 1, 2.0,
+                                  n1, 1.0, 0, st)
+
+        def bwd_w():  # noqa: F811
+            lib.pp_backward_weight_f32(P(x), P(gy), P(GT), P(tws), twb, B, I, O, 1, table, 1, 2.0,
+                                       n1, 1.0, 0, st)
+            lib.pp_grid_table_grad_f32(P(GT), P(gw), I, O, n, S, d, 2.0, nodes, 1.0, table, st)
     times = {"fwd": time_kernel(fwd, iters), "bwd_w": time_kernel(bwd_w, iters)}
     if not first:
         times["bwd_x"] = time_kernel(bwd_x, iters)
@@ -204,15 +226,20 @@ def roofline_hbm(B, dev):
     algorithmic bytes (every operand touched once per pass, dense gw) over the sum of the
     entry-point times, as a fraction of 8 TB/s."""
     out = []
-    for name, disc, n, S, I, O, kind, first, ref_rows in (
-            ("cfg3 hidden (discontinuous n=1 200->200 S=150)", True, 1, 150, 200, 200, "normal", False, 1000),
-            ("cfg4 input (discontinuous n=2 16->1000 S=128)", True, 2, 128, 16, 1000, "char", True, 256),
+    for name, disc, n, S, I, O, kind, first, ref_rows, table in (
+            ("cfg3 hidden (discontinuous n=1 200->200 S=150)", True, 1, 150, 200, 200, "normal", False, 1000, 0),
+            ("cfg4 input (discontinuous n=2 16->1000 S=128)", True, 2, 128, 16, 1000, "char", True, 256, 0),
+            # the same layer told that its inputs are characters (layer.assume_input_grid(128)):
+            # table build + n = 1 kernels + map back, all inside the timed launches
+            ("cfg4 input in table form (inputs declared on the 128-point character grid)", True, 2, 128,
+             16, 1000, "char", True, 256, 128),
             # the same cfg3 layer as the reference's select_network really builds it: hidden layers get
             # n_hidden = cfg.net.n_in = 2 (networks.py:870; SURVEY.md 8a "reference quirk"), K = 300
             ("cfg3 hidden as select_network builds it (discontinuous n=2 200->200 S=150)", True, 2, 150,
-             200, 200, "normal", False, 1000)):
+             200, 200, "normal", False, 1000, 0)):
         for rows in (B, ref_rows):
-            t, methods, K = time_layer(rows, disc, n, S, I, O, dev, kind, first, iters=10)
+            t, methods, K = time_layer(rows, disc, n, S, I, O, dev, kind, first, iters=10,
+                                       table=table)
             W = I * K * O
             by = 4 * ((2 * rows * I + 2 * rows * O + 2 * W) if first
                       else (3 * rows * I + 2 * rows * O + 3 * W))
@@ -386,6 +413,8 @@ def main():
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="N > 1: keep graph replay + flat all-reduce without timing the hook path")
     ap.add_argument("--no-hbm-layers", action="store_true", help="skip the roofline_hbm object")
+    ap.add_argument("--no-char-table", action="store_true",
+                    help="skip the extra timing of the step with the input layer in table form")
     ap.add_argument("--cpu-rows", type=int, default=4096)
     ap.add_argument("--train-optimizer", choices=("sparse_lion", "lion", "adam"),
                     default="sparse_lion",
@@ -563,6 +592,29 @@ def main():
         other_dt = timed(other, args.steps)
         eager_dt, graph_dt = (dt, other_dt) if run is compute else (other_dt, dt)
 
+    # The same step with the input layer told that its inputs are characters
+    # (layer.assume_input_grid(128): table form, include/pp_hip.h pp_grid_table_f32).  Reported
+    # beside the headline, which stays on the general kernels -- the statement about the inputs
+    # is the caller's, the reference's layer has no such argument.
+    table_dt = table_launch = None
+    if world == 1 and not args.no_char_table:
+        first_layer = net.model[0]
+        first_layer.assume_input_grid(128)
+        try:
+            for _ in range(3):
+                compute()
+            tab_run, table_launch = compute, "eager"
+            if graph is not None:
+                g2 = capture()
+                probe = max(5, min(20, args.steps))
+                if timed(g2.replay, probe) < timed(compute, probe):
+                    tab_run, table_launch = g2.replay, "hipgraph"
+            for _ in range(args.warmup):
+                tab_run()
+            table_dt = timed(tab_run, args.steps)
+        finally:
+            first_layer.assume_input_grid(0)
+
     train_cps = None
     if args.train_steps > 0:
         if reducer is None and world > 1:
@@ -601,6 +653,13 @@ def main():
         if eager_dt is not None:
             out["eager_ms_per_step"] = round(eager_dt / args.steps * 1e3, 4)
             out["hipgraph_ms_per_step"] = round(graph_dt / args.steps * 1e3, 4)
+        if table_dt is not None:
+            out["char_table"] = {
+                "ms_per_step": round(table_dt / args.steps * 1e3, 4),
+                "value": round(B * args.steps / table_dt, 1), "launch": table_launch,
+                "note": "same step, input layer in table form (net.model[0].assume_input_grid(128): "
+                        "inputs declared on the 128-point character grid; table build and the map "
+                        "back of the gradient inside the step); not the headline"}
         if train_cps is not None:
             # cross entropy + optimizer step (graph replay at N=1)
             out["train_chars_per_s"] = round(train_cps, 1)

@@ -31,10 +31,10 @@ def _inputs(B, I, O, n, S, disc, seed):
 TABLE_CASES = [
     (False, 2, 128, 16, 250, 16384),   # cfg2 input layer at the bench batch
     (True, 2, 128, 16, 1000, 4096),    # cfg4 input layer (K = 256: two parts without the table)
-    (False, 2, 128, 16, 200, 1000),    # cfg1 input layer at the reference's batch
-    (False, 3, 2, 10, 64, 777),        # few segments: 64 grid points a segment
-    (True, 1, 150, 16, 72, 513),       # n = 1, S not a divisor of the grid
-    (False, 5, 7, 3, 4, 33),           # high order, tiny
+    (False, 2, 128, 16, 200, 2048),    # cfg1 input layer at the smallest batch that takes the table
+    (False, 3, 2, 10, 64, 2777),       # few segments: 64 grid points a segment
+    (True, 1, 150, 16, 72, 2049),      # n = 1, S not a divisor of the grid
+    (False, 5, 7, 3, 4, 2100),         # high order, tiny
 ]
 
 
@@ -46,6 +46,7 @@ def test_table_form_matches_general_path_and_oracle(case):
     assert PF.on_input_grid(x) and not PF.on_input_grid(x + 1e-3)
     spec = PF.make_spec(n, S, disc)
     tspec = dataclasses.replace(spec, input_grid=128)
+    assert PF.use_table_form(tspec, B) and not PF.use_table_form(tspec, 2047)
     wd0 = w.cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1)
     def run(fn):
         xd = x.cuda().requires_grad_(True)
@@ -138,7 +139,12 @@ def test_high_order_mlp_with_the_input_layer_in_table_form():
     assert rel_err(y1.cpu(), y0.cpu()) <= 2e-5
     for a, b in zip(g1, g0):
         assert rel_err(a.cpu(), b.cpu()) <= 5 * TOL
+    # under 16 rows per grid point the statement changes nothing (the table would cost more
+    # than it saves): same bits as the general path
+    xs, gs = x[:1000].contiguous(), gy[:1000].contiguous()
+    ya = net(xs)
     first.assume_input_grid(0)
+    assert torch.equal(net(xs), ya)
     y2, _ = run()
     assert torch.equal(y2, y0)
 

@@ -14,4 +14,5 @@ d=json.load(open("$D/bench.json"))
 print(d["ms_per_step"], d["value"], d.get("eager_ms_per_step"), d.get("hipgraph_ms_per_step"), d["train_chars_per_s"])
 for r in d["roofline_hbm"]: print(r["layer"], r["rows"], r["launch_us"], r["frac"], r["auto_methods"])
 print(d["roofline"]["frac"], d["roofline"]["launch_us"])
+print("char_table", d.get("char_table"))
 PY
