@@ -235,8 +235,9 @@ int pp_backward_weight_f32(const float* x, const float* gy, float* gw_t, void* w
  * (dense [I][K][O], every element written, grid points added in ascending order).
  * points: a power of two <= 128; length must be 2.  Replaces nothing in the reference by itself:
  * same y and gw_t as the general entry points on grid inputs (up to fp32 summation order).
- * Measured (MI355X, 16384 rows): 16 -> 250, n = 2: forward + LayerNorm 36 -> 22 us, weight gradient
- * 37 -> 28 us; 16 -> 1000, n = 2 (K = 256): forward 56 -> 44 us, weight gradient 108 -> 50 us. */
+ * Measured (MI355X, 16384 rows, table build and map back included): 16 -> 250, n = 2: forward +
+ * LayerNorm 35 -> 26 us, weight gradient level; 16 -> 1000, n = 2 (K = 256): forward 57 -> 52 us,
+ * weight gradient 110 -> 58 us.  At a few hundred rows the table costs more than it saves. */
 int pp_grid_table_supported(int I, int O, int n, int S, int discontinuous, float length,
                             int points);
 int pp_grid_table_f32(const float* w_t, float* table, int I, int O, int n, int S, int discontinuous,
