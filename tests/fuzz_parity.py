@@ -168,6 +168,21 @@ def run_case(case, rng=None):
         b2, s2 = _compare(got, ref, ref32, sums)
         bad += [f"forced {f}/{bx}/{bw}: {m}" for m in b2]
         soft += [f"forced {f}/{bx}/{bw}: {m}" for m in s2]
+    if dist == "char":
+        # character inputs: the layer in its table form (csrc/pp_table.hip), whatever the batch
+        # (the module switches to it from 16 rows per grid point; here the kernels are the point)
+        import dataclasses
+        PF = _pf()
+        tspec = dataclasses.replace(PF.make_spec(n, S, disc), input_grid=128)
+        xd, gyd = x.cuda(), gy.cuda()
+        w_t = w.cuda().permute(1, 2, 0).contiguous()
+        T = PF.grid_table(w_t, tspec)
+        got = {"y": PF.forward_raw(xd, T, PF.table_spec(tspec))[0].cpu()}
+        gt = PF.backward_weight_raw(xd, gyd, (I, 128, O), PF.table_spec(tspec))
+        got["gw"] = PF.grid_table_grad(gt, tuple(w_t.shape), tspec).permute(2, 0, 1).cpu()
+        b3, s3 = _compare(got, ref, ref32, sums)
+        bad += [f"table form: {m}" for m in b3]
+        soft += [f"table form: {m}" for m in s3]
     return bad, soft
 
 
