@@ -100,6 +100,8 @@ bool matrix_core_fwd(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 
 // The row-tile forward where it is the faster kernel and its scratch (per-row records, partial
 // outputs) is at hand.
 bool tile_fwd(const PPShape& sh, bool have_ws) { return pp_tile_fwd_preferred(sh) && have_ws; }
+// ... with a normalisation fused behind the layer
+bool tile_fwd_norm(const PPShape& sh) { return pp_tile_fwd_preferred(sh, true); }
 bool matrix_core_bwd_x(const PPShape& sh) { return dense_preferred(sh) && sh.B >= 256; }
 
 }  // namespace
@@ -582,7 +584,7 @@ int pp_forward_layer_norm_f32(const float* x, const float* w_t, float* y, float*
   PPShape sh;
   int rc = make_shape(sh, B, I, O, n, S, discontinuous, length, out_scale);
   if (rc != PP_OK) return rc;
-  if (packed && !matrix_core_fwd(sh) && tile_fwd(sh, true) && sh.O <= 1024) {
+  if (packed && !matrix_core_fwd(sh) && tile_fwd_norm(sh) && sh.O <= 1024) {
     // mode 3: `packed` is the row-tile kernel's scratch; the kernel that sums the partial
     // outputs normalises the rows
     if (packed_bytes < pp_tile_fwd_workspace_bytes(sh, true)) return PP_ERR_WORKSPACE;
@@ -611,7 +613,7 @@ int pp_forward_layer_norm_supported(int B, int I, int O, int n, int S, int disco
   if (make_shape(sh, B, I, O, n, S, discontinuous, length, 1.0f) != PP_OK) return 0;
   if (pp_h2_fwd_ln_supported(sh) && pp_bf3_bwd_x_supported(sh) && matrix_core_fwd(sh))
     return 1;
-  if (!matrix_core_fwd(sh) && tile_fwd(sh, true) && sh.O <= 1024) return 3;
+  if (!matrix_core_fwd(sh) && tile_fwd_norm(sh) && sh.O <= 1024) return 3;
   // layers the gather kernels serve (many segments, first layers, lengths off the matrix-core
   // path): fused there too
   if (!matrix_core_fwd(sh) && pp_gather_ln_supported(sh)) return 2;

@@ -50,7 +50,7 @@ hipError_t pp_launch_fwd_slab(const float* x, const float* wt, float* y, int32_t
 
 // ---- row-tile path: accumulators of a tall row tile in registers, slab in LDS (pp_tile.hip) ----
 bool pp_tile_fwd_supported(const PPShape& sh);
-bool pp_tile_fwd_preferred(const PPShape& sh);
+bool pp_tile_fwd_preferred(const PPShape& sh, bool with_norm = false);
 size_t pp_tile_fwd_workspace_bytes(const PPShape& sh, bool with_norm);
 // backward-input on the same tiles (n >= 2, I % 4 == 0)
 bool pp_tile_bwd_x_supported(const PPShape& sh);

@@ -726,13 +726,18 @@ bool pp_tile_fwd_supported(const PPShape& sh) { return tile_plan(sh).ok; }
 //   cfg3 with n=2 (K=300)             2048: 51 vs 40 (loses), 4096: 64 vs 88, 16384: 147 vs 248
 //   cfg4 input (n=2 16->1000 K=256)   8192: 53 vs 47 (loses), 16384: 57 vs 88
 //   cfg1 input (n=2 16->200 K=129)    loses at every batch (39 vs 21 at 16384)
+//   cfg4 input as a table (n=1 16->1000 K=128, pp_table.hip)  16384: 36 vs 44, 8192: 43 vs 26 (loses)
 // i.e. it pays once the gather kernel's L1 traffic B*I*n*O*4 passes ~0.8 GB, and for the
-// few-input layers (three launches and the output tile's write-out over 16 inputs) ~2 GB.
-bool pp_tile_fwd_preferred(const PPShape& sh) {
+// few-input layers (three launches and the output tile's write-out over 16 inputs) ~2 GB --
+// or ~1 GB where the (tile, chunk) pairs fill the chip without an input split, so that the
+// tiles go straight to y (no partial outputs to write and add up).
+// (with a normalisation behind the layer the tiles go through the partial buffer either way)
+bool pp_tile_fwd_preferred(const PPShape& sh, bool with_norm) {
   const TilePlan p = tile_plan(sh);
   if (!p.ok || sh.K < 64 || sh.O < 64) return false;
   const double gather_bytes = 4.0 * sh.B * sh.I * sh.n * sh.O;
-  return gather_bytes >= (sh.I >= 64 ? 0.8e9 : 2.0e9);
+  if (sh.I >= 64) return gather_bytes >= 0.8e9;
+  return gather_bytes >= (p.nsplit == 1 && !with_norm ? 1.0e9 : 2.0e9);
 }
 
 // records | partial outputs (when the inputs are split, or a normalisation follows)
