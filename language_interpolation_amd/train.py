@@ -355,6 +355,9 @@ class CharWindows:
         self.n = self.buf.numel() - (features + 1)
         if self.n <= 0:
             raise ValueError("text shorter than one window")
+        # every byte below 128: every x this dataset hands out is one of the 128 grid points
+        # (c - 63.5)/64, and the input layer may run in table form (declare_character_inputs)
+        self.ascii_only = bool((self.buf < 128).all().item())
         self._ar = torch.arange(features, device=self.buf.device)
 
     def __len__(self):
@@ -399,6 +402,22 @@ class CharSequences(CharWindows):
             win = self.buf[idx.unsqueeze(1) + torch.arange(self.features + 1)].long()
         win = win.unsqueeze(2)
         return win[:, :-1], win[:, 1:], idx
+
+
+def declare_character_inputs(net: nn.Module, points: int = 128):
+    """Tell the first polynomial layer of `net` (HighOrderMLP, or the Sequential of
+    model_type high_order_input) that its inputs are character codes on the `points`-point
+    grid, so that its forward and weight gradient run in table form (layers.assume_input_grid;
+    csrc/pp_table.hip).  Only for a dataset that guarantees it: CharWindows.ascii_only.
+    Returns the layer, or None when there is none / it has no table form."""
+    seq = net.model if isinstance(getattr(net, "model", None), nn.Sequential) else net
+    first = seq[0] if isinstance(seq, nn.Sequential) and len(seq) else None
+    if first is None or not hasattr(first, "assume_input_grid"):
+        return None
+    try:
+        return first.assume_input_grid(points)
+    except ValueError:
+        return None
 
 
 def make_data(cfg: Config, text, device="cuda") -> CharWindows:
@@ -532,6 +551,8 @@ def main(argv=None):
     text = open(args.text, "rb").read() if args.text else synthetic_text(1 << 20)
     module = prediction_net(cfg, device="cuda")
     data = make_data(cfg, text, device="cuda")
+    if cfg.net.model_type != "mamba" and data.ascii_only:
+        declare_character_inputs(module.model)  # the data set vouches for the grid
     hist = fit(module, data, args.steps, cfg.batch_size, log_every=max(1, args.steps // 10),
                gradient_clip=cfg.get("gradient_clip"), graph=args.graph)
     print(json.dumps({"final_loss": hist[-1][0], "final_acc": hist[-1][1], "steps": len(hist)}))

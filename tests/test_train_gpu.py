@@ -78,6 +78,30 @@ def test_fit_learns_a_repeating_text():
     assert hist[-1][1] > 0.6
 
 
+def test_training_with_the_input_layer_in_table_form_follows_the_general_path():
+    """CharWindows vouches for the character grid (ascii_only); with the input layer declared
+    (train.declare_character_inputs) ten Adam steps at 4096 rows stay on the general path's
+    losses, and a text with a byte >= 128 is not vouched for."""
+    from language_interpolation_amd import train as T
+    cfg = T.load_config(CFG, ["net=baseline_small_250", "net.hidden.width=64",
+                              "net.hidden.layers=1", "optimizer=adam", "optimizer.lr=1e-3",
+                              "batch_size=4096"])
+    text = T.synthetic_text(20000, seed=3)
+    data = T.CharWindows(text, cfg.net.features, device="cuda")
+    assert data.ascii_only
+    assert not T.CharWindows(text + bytes([200]) * 40, cfg.net.features, device="cuda").ascii_only
+    hists = []
+    for declare in (False, True):
+        torch.manual_seed(4)
+        module = T.ASCIIPredictionNet(cfg, device="cuda")
+        if declare:
+            layer = T.declare_character_inputs(module.model)
+            assert layer is module.model.model[0] and layer._spec.input_grid == 128
+        hists.append(T.fit(module, data, steps=10, batch_size=cfg.batch_size, seed=5))
+    for (la, _), (lb, _) in zip(*hists):
+        assert abs(la - lb) <= 2e-4 * max(1.0, abs(la)), (la, lb)
+
+
 def test_high_order_input_network_and_sparse_lion_step():
     from language_interpolation_amd import train as T
     torch.manual_seed(2)
