@@ -283,9 +283,14 @@ def train_chars_per_s(net, dev, B, steps, world, reducer, graph, optimizer="spar
     kernel per step, train.Lion) or Adam.  One process: the step is replayed from a HIP graph
     (train.GraphedTrainStep); several: eager launches with the RCCL all-reduce of the
     gradients overlapping the backward."""
-    from language_interpolation_amd.train import CharWindows, GraphedTrainStep, Lion
+    from language_interpolation_amd.train import (CharWindows, GraphedTrainStep, Lion,
+                                                  declare_character_inputs)
 
     data = CharWindows(raven_like_text(1 << 20, seed=7), 16, device=dev)
+    if data.ascii_only:
+        # as train.main does: the data set vouches for the character grid, the input layer
+        # runs in table form (this figure only; the headline step is timed before, on float x)
+        declare_character_inputs(net)
     gen = torch.Generator(device=dev).manual_seed(11)
     module = _TrainModule(net)
     graph = graph and reducer is None
@@ -664,6 +669,7 @@ def main():
             # cross entropy + optimizer step (graph replay at N=1)
             out["train_chars_per_s"] = round(train_cps, 1)
             out["train_optimizer"] = args.train_optimizer
+            out["train_input_layer"] = "table form (the data set vouches for the character grid)"
         hb = step_bytes(B)
         out["hbm_roofline"] = {"algorithmic_bytes_per_step": hb,
                                "achieved_GBs": round(hb / (dt / args.steps) * 1e-9, 1),
