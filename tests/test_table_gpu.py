@@ -111,7 +111,8 @@ def test_grid_table_entry_points_against_torch():
 
 def test_high_order_mlp_with_the_input_layer_in_table_form():
     """The bench network with its first layer told about the character grid: same outputs and
-    gradients as without (tolerance), graph-capturable, and the statement survives set_methods."""
+    gradients as without (tolerance), and the statement survives set_methods (bench.py replays
+    this step from a HIP graph: `char_table.launch`)."""
     import language_interpolation_amd as lia
     PF = _pf()
     torch.manual_seed(10)
